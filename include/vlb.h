@@ -1,0 +1,215 @@
+/* libvlb C-ABI: the MI355X (gfx950) compute boundary of the phantom_vlb fine-tuning hot path.
+ *
+ * The reference (courtois-neuromod/phantom_vlb) is pure Python and has NO FFI of its own
+ * (SURVEY.md 2.1): every entry point below replaces arithmetic that the reference reaches
+ * through torch / transformers / peft / timm / flash_attn calls inside
+ *   src/litmodule/videollama2_vlb_litmodule.py:229-306   (forward + training_step)
+ *   src/utils.py:40-73                                   (HRFConvolveLayer, RidgeRegressionLayer)
+ * and each declaration cites the call it stands in for.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - All pointers are DEVICE pointers unless the name ends in _host.  The caller owns every
+ *     buffer (inputs, outputs, workspaces); the library never allocates or frees.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, nothing syncs.
+ *   - Return 0 on success, negative VLB_ERR_* otherwise; vlb_last_error() gives a
+ *     thread-local message.  Nothing throws or aborts across the boundary.
+ *   - "bf16" buffers are raw 16-bit bfloat16; row-major; `ld*` are row strides in ELEMENTS.
+ *   - Functions are stateless and re-entrant; one process per GPU.
+ */
+#ifndef VLB_H
+#define VLB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLB_OK 0
+#define VLB_ERR_INVALID (-1) /* bad shape / alignment / argument */
+#define VLB_ERR_LAUNCH (-2)  /* HIP launch error */
+
+#define VLB_ABI_VERSION 1
+
+/* epilogue activations for vlb_gemm_bf16 / vlb_layernorm_fwd */
+#define VLB_ACT_NONE 0
+#define VLB_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): CLIP MLP (transformers modeling_clip.py CLIPMLP) */
+#define VLB_ACT_GELU 2       /* erf GELU: STC connector readout */
+#define VLB_ACT_SILU 3       /* SE fc1, sampler */
+
+int vlb_abi_version(void);
+const char* vlb_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contraction (MFMA).  Replaces every nn.Linear / 1x1-conv / Conv3d-as-GEMM on the path:
+ *   transformers modeling_mistral.py:41-47,134-137 (q/k/v/o, gate/up/down),
+ *   modeling_clip.py CLIPAttention/CLIPMLP linears, patch-embed conv (as im2col GEMM),
+ *   timm RegStage 1x1 convs, STCConnector sampler/readout,
+ *   and peft LoRA  y += s*B(A(x))  through the second operand pair (A2 = s*x*A^T, W2 = B).
+ *
+ *   C[M,N] = act( A[M,K] . W[N,K]^T  +  A2[M,K2] . W2[N,K2]^T  +  bias[N] ) + residual[M,N]
+ *
+ * A, W, A2, W2, C, residual bf16; bias bf16 or NULL; fp32 accumulate.  K, K2 multiples of 8.
+ * The library picks a 256x256 / 256x128 LDS-DMA MFMA kernel when N and K allow it, else a
+ * bounds-checked 64x64 MFMA kernel.  residual may alias C.
+ */
+int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                  const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                  const void* W2, int ldw2, int K2, void* stream);
+
+/* Which kernel vlb_gemm_bf16 picks for a shape: 0 = generic 64x64, 1 = 256x256, 2 = 256x128. */
+int vlb_gemm_kernel_choice(int M, int N, int K, int K2);
+
+/* out[C,R] = in[R,C]^T (bf16).  Used once per frozen weight to lay down W^T for dgrad. */
+int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention (flash-style, LDS-staged K/V tiles, fp32 online softmax).
+ * Replaces flash_attention_2 / eager attention of modeling_mistral.py:96-178 (causal, GQA,
+ * key padding mask) and modeling_clip.py CLIPAttention (non-causal, no mask).
+ *   q: [B,S,Hq,D] with row stride ldq (elements between consecutive tokens), k/v likewise with
+ *   Hkv heads; out [B,S,Hq,D] stride ldo.  key_mask: [B,S] bytes (1 = attend) or NULL.
+ *   lse: [B,Hq,S] fp32 log-sum-exp (natural log, of scaled scores) or NULL; needed by bwd.
+ *   D in {64,128}.
+ */
+int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                      float* lse, const uint8_t* key_mask, int B, int S, int Hq, int Hkv, int D, int causal,
+                      float scale, void* stream);
+
+/* Backward of the above. dq/dk/dv have the layout/strides of q/k/v.  delta: [B,Hq,S] fp32 workspace.
+ * dq_acc: [B,S,Hq,D] fp32 workspace (zeroed by the call). */
+int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
+                      int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,
+                      int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B, int S,
+                      int Hq, int Hkv, int D, int causal, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row normalisations (HBM-bound, 16-byte vector loads, fp32 statistics).
+ */
+/* MistralRMSNorm, modeling_mistral.py:182-196: y = w * bf16(x * rsqrt(mean(x^2)+eps)). */
+int vlb_rmsnorm_fwd(const void* x, const void* w, void* y, int rows, int dim, float eps, void* stream);
+/* dx = rmsnorm backward (+ optional accumulate into dx_accum_in: dx = dx_in + ...); dw not needed
+ * (norm weights are frozen in every LoRA configuration). */
+int vlb_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dx_in, void* dx, int rows, int dim,
+                    float eps, void* stream);
+/* nn.LayerNorm / timm LayerNorm2d on channels-last rows, fused tail:
+ *   y = act( LN(x)*w + b + residual ).  residual may be NULL.  Replaces CLIP layer_norm1/2,
+ *   pre_layrnorm, and ConvNormAct(norm=LayerNorm2d, act=SiLU) of timm RegStage. */
+int vlb_layernorm_fwd(const void* x, const void* w, const void* b, const void* residual, void* y, int rows, int dim,
+                      float eps, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder element-wise ops.
+ */
+/* apply_rotary_pos_emb, modeling_mistral.py:51-81, in place on `heads` heads of width D starting at x
+ * (token stride ld). cos/sin: [S, D/2] fp32 tables (positions 0..S-1).  sign=+1 forward, -1 backward. */
+int vlb_rope_inplace(void* x, int ld, const float* cos_t, const float* sin_t, int B, int S, int heads, int D,
+                     int sign, void* stream);
+/* MistralMLP gate: out[r, j] = silu(gu[r, j]) * gu[r, ff + j]   (gu = [gate | up], row stride 2*ff). */
+int vlb_swiglu_fwd(const void* gu, void* out, int rows, int ff, void* stream);
+/* dgu from dout, recomputing silu from gu. */
+int vlb_swiglu_bwd(const void* gu, const void* dout, void* dgu, int rows, int ff, void* stream);
+/* y = a + b (bf16), n elements (multiple of 8). */
+int vlb_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vision ingest + CLIP embeddings (modeling_clip.py:138-219; litmodule :267 per-sample .to(bf16)).
+ */
+/* vision fp32 [N,3,H,W] -> patch rows bf16 [N*(H/P)*(W/P), Kpad] with K = 3*P*P zero-padded to Kpad;
+ * fuses the fp32->bf16 cast of training_step:267 into the im2col of the stride-P patch conv. */
+int vlb_patchify(const float* vision, void* patches, int N, int H, int W, int P, int Kpad, void* stream);
+/* tokens[n, 0] = cls + pos[0]; tokens[n, 1+i] = patch_emb[n*G+i] + pos[1+i]   (all bf16, width D) */
+int vlb_vit_assemble(const void* patch_emb, const void* cls, const void* pos, void* tokens, int N, int G, int D,
+                     void* stream);
+/* copy rows dropping the CLS token: out[n, i] = tokens[n, 1+i] */
+int vlb_drop_cls(const void* tokens, void* out, int N, int G, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * STC connector pieces (VideoLLaMA2 projector + timm RegStage; channels-last rows).
+ */
+/* depthwise 3x3, stride 1, pad 1, no bias.  x,y: [N,H,W,C] bf16; w: [C,9] bf16 (= conv2.conv.weight). */
+int vlb_dwconv3x3(const void* x, const void* w, void* y, int N, int H, int W, int C, void* stream);
+/* squeeze: mean over H*W -> [N,C] bf16. */
+int vlb_se_pool(const void* x, void* pooled, int N, int HW, int C, void* stream);
+/* excite: y = x * sigmoid(gate[n,c]) */
+int vlb_se_scale(const void* x, const void* gate, void* y, int N, int HW, int C, void* stream);
+/* im2col for Conv3d(k=2,s=2,p=1): x [B,T,H,W,C] -> cols [B*T2*H2*W2, 8*C], tap order (kt,kh,kw,c). */
+int vlb_im2col3d_k2s2p1(const void* x, void* cols, int B, int T, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token splice (VideoLLaMA2 prepare_inputs_labels_for_multimodal) and the HRF weight mask
+ * (VLBLitModule.make_weight_mask, litmodule :178-203) - one launch each instead of Python loops.
+ */
+/* ids: [B,L] int64 with one video_id per row. embeds out [B, L-1+Nv, D]; key_mask out [B, L-1+Nv] bytes
+ * (ids != 0, left-extended with ones).  Returns VLB_ERR_INVALID via err_flag[0] != 0 if a row lacks
+ * exactly one video token (flag is device memory, checked by the caller lazily). */
+int vlb_splice_embed(const int64_t* ids, const void* embed_w, const void* video_tokens, void* embeds,
+                     uint8_t* key_mask, int* err_flag, int B, int L, int Nv, int D, int64_t video_id, int vocab,
+                     void* stream);
+/* wmask[b, :] = [left zeros][vis_w[b,f] x tokens_per_frame][2+inst zeros][lang_w[b,:dialog]][4+pad zeros]
+ * padvals int64 [B,3] = (pad_len, inst_len, dialog_len); vis_w f64 [B,F]; lang_w f64 [B,Lw]; out f32 [B,S].
+ * round_bf16 != 0 rounds every weight to bf16 first, as the reference does (.to(self.config.dtype), :190-194). */
+int vlb_weight_mask(const int64_t* padvals, const double* vis_w, const double* lang_w, float* wmask, int B, int F,
+                    int Lw, int tokens_per_frame, int S, int round_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Brain head (litmodule :245-254,302; utils.py:56,66-71), fused:
+ *   hidden bf16 [B,S,E] --LN1--> --sum_s w[b,s]*.--> pooled --LN2--> z (x keep_mask/(1-p)) --Linear--> pred
+ *   loss = mean((pred-y)^2) + lambda*||W||_F^2
+ * The normalised [B,S,E] tensor is never written; tokens whose weight is zero are skipped.
+ * Caller-allocated buffers (fp32 unless noted):
+ *   ws          scratch of vlb_head_ws_floats(B,S,E,V) floats (shared by fwd and bwd)
+ *   saved for backward: stats [B,S,2] (LN1 mean, rstd; rows with w==0 untouched), pooled_raw [B,E],
+ *   sumw [B], zhat [B,E] (LN2 output before affine), ln2_rstd [B], z [B,E] bf16 (head input of the
+ *   ridge layer, rounded to bf16 as autocast does), pred [B,V].
+ *   keep_scale: [B,E] dropout keep-mask already divided by (1-p), or NULL (eval / p=0).
+ *   y: [B,V] fp32 targets.  loss_terms[3] = {mse, l2, mse+l2}.
+ */
+int vlb_head_partial_rows(int S);
+int64_t vlb_head_ws_floats(int B, int S, int E, int V);
+int vlb_head_fwd(const void* hidden, const float* wmask, const void* ln1_w, const void* ln1_b, const void* ln2_w,
+                 const void* ln2_b, const void* ridge_w, const void* ridge_b, const float* y, const float* keep_scale,
+                 float* ws, float* stats, float* pooled_raw, float* sumw, float* zhat, float* ln2_rstd, void* z,
+                 float* pred, float* loss_terms, int B, int S, int E, int V, float eps, float l2_lambda, void* stream);
+/* Gradients of loss wrt head parameters (fp32 outputs, overwritten) and, when dhidden != NULL, wrt
+ * hidden (bf16 [B,S,E]).  loss_scale multiplies the mse term's gradient (1/world under data
+ * parallelism); l2_scale the ridge penalty's.  dz_ws, dpooled_ws: [B,E] fp32 scratch. */
+int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, const void* ln2_w, const void* ridge_w,
+                 const float* y, const float* keep_scale, const float* stats, const float* pooled_raw,
+                 const float* sumw, const float* zhat, const float* ln2_rstd, const void* z, const float* pred,
+                 float* d_ridge_w, float* d_ridge_b, float* d_ln2_w, float* d_ln2_b, float* d_ln1_w, float* d_ln1_b,
+                 float* ws, float* dz_ws, float* dpooled_ws, void* dhidden, int B, int S, int E, int V, float eps,
+                 float l2_lambda, float loss_scale, float l2_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LoRA weight gradients (peft: only A,B train).  dW[N,K] (fp32, accumulate if beta!=0) =
+ *   alpha * sum_m  G[m, n] * X[m, k]      G: [M,N] bf16 (ldg), X: [M,K] bf16 (ldx); N <= 64.
+ * Used as dA = s*(dY B)^T X  (N=r) and dB^T = s*(X A^T)^T dY (N=r, K=out): both skinny-N.
+ * ws: fp32 [vlb_wgrad_splits(M), N, K] partial slabs.
+ */
+int vlb_wgrad_splits(int M);
+int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
+                     float alpha, float beta, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser (litmodule :345-379 AdamW + CosineAnnealingLR; Trainer gradient_clip_val).
+ */
+/* sumsq[0] += sum(g^2)   (fp32 grads; sumsq zeroed by caller once per step) */
+int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* fused clip + AdamW on an fp32 master with fp32 moments; writes the bf16 compute copy when
+ * param_bf16 != NULL.  clip coefficient = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) read on device
+ * (max_norm <= 0 disables clipping).  step counts from 1. */
+int vlb_adamw_step(float* master, void* param_bf16, const float* grad, float* m, float* v, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
+                   float max_norm, void* stream);
+
+/* misc */
+int vlb_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLB_H */

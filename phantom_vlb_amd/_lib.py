@@ -1,0 +1,83 @@
+"""ctypes binding of libvlb.so (the C-ABI declared in include/vlb.h).
+
+The product path has NO fallback: if the HIP library is missing or an entry point is absent,
+import fails loudly.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlb.so")
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/vlb.h one to one
+SIGNATURES = {
+    "vlb_abi_version": [],
+    "vlb_last_error": [],
+    "vlb_gemm_bf16": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P],
+    "vlb_gemm_kernel_choice": [I, I, I, I],
+    "vlb_transpose_bf16": [P, P, I, I, P],
+    "vlb_attention_fwd": [P, I, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
+    # TODO(bwd) "vlb_attention_bwd": [P, I, P, I, P, I, P, I, P, I, P, P, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
+    "vlb_rmsnorm_fwd": [P, P, P, I, I, F, P],
+    "vlb_rmsnorm_bwd": [P, P, P, P, P, I, I, F, P],
+    "vlb_layernorm_fwd": [P, P, P, P, P, I, I, F, I, P],
+    "vlb_rope_inplace": [P, I, P, P, I, I, I, I, I, P],
+    "vlb_swiglu_fwd": [P, P, I, I, P],
+    "vlb_swiglu_bwd": [P, P, P, I, I, P],
+    "vlb_add_bf16": [P, P, P, L, P],
+    "vlb_patchify": [P, P, I, I, I, I, I, P],
+    "vlb_vit_assemble": [P, P, P, P, I, I, I, P],
+    "vlb_drop_cls": [P, P, I, I, I, P],
+    "vlb_dwconv3x3": [P, P, P, I, I, I, I, P],
+    "vlb_se_pool": [P, P, I, I, I, P],
+    "vlb_se_scale": [P, P, P, I, I, I, P],
+    "vlb_im2col3d_k2s2p1": [P, P, I, I, I, I, I, P],
+    "vlb_splice_embed": [P, P, P, P, P, P, I, I, I, I, L, I, P],
+    "vlb_weight_mask": [P, P, P, P, I, I, I, I, I, I, P],
+    "vlb_head_partial_rows": [I],
+    "vlb_head_ws_floats": [I, I, I, I],
+    "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P],
+    "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P],
+    # TODO(bwd) "vlb_wgrad_splits": [I],
+    # TODO(bwd) "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, P],
+    "vlb_grad_sumsq": [P, L, P, P],
+    "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
+    "vlb_cast_f32_to_bf16": [P, P, L, P],
+    "vlb_cast_bf16_to_f32": [P, P, L, P],
+}
+_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64}
+
+
+class VlbError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C phantom_vlb_amd/csrc`.  phantom_vlb_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"libvlb.so does not export {name}: rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.vlb_abi_version() != 1:
+        raise ImportError("libvlb.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise VlbError(f"{what} failed ({rc}): {lib.vlb_last_error().decode()}")

@@ -1,0 +1,282 @@
+"""VideoLLaMA2 backbone (CLIP tower -> STC connector -> token splice -> Mistral decoder) on libvlb.
+
+Host-side mirror of what the reference reaches through ``self.nnmodule(input_ids, attention_mask,
+output_hidden_states=True, images=x_video)`` (src/litmodule/videollama2_vlb_litmodule.py:231-236):
+the un-vendored ``Videollama2MistralForCausalLM``.  Only the piece the loss reads is computed -
+``hidden_states[-1]`` (post final RMSNorm); the lm_head logits and the 33 hidden-state copies the
+reference materialises are never used by the loss and are dropped.
+
+Layout (MI355X-first): every activation is a 2-D [tokens, channels] bf16 matrix (channels-last),
+so 1x1 convs, the patch conv, Conv3d (via im2col) and all linears are one TN GEMM kernel;
+q/k/v and gate/up are fused into single weights; frozen weights also keep a transposed copy for
+the dgrad GEMMs of the LoRA configuration (288 GB of HBM makes that free).
+Weights are addressed by their upstream state-dict names so real checkpoints can be loaded.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .geometry import Geometry, VIDEO_TOKEN_ID
+
+BF16 = torch.bfloat16
+V_PRE = "model.vision_tower.vision_tower.vision_model"
+M_PRE = "model.mm_projector"
+
+
+def _bf(t, dev):
+    return t.detach().to(device=dev, dtype=BF16).contiguous()
+
+
+class Weights:
+    """Kernel-ready bf16 weights built from an upstream-named state dict (any dtype / device)."""
+
+    def __init__(self, g: Geometry, sd: dict, device, keep_transposed: bool = False):
+        self.g = g
+        self.dev = device
+        d = device
+        # ---- CLIP tower
+        w = sd[f"{V_PRE}.embeddings.patch_embedding.weight"].reshape(g.vit_dim, -1)
+        wp = torch.zeros(g.vit_dim, g.patch_k_padded, dtype=w.dtype, device=w.device)
+        wp[:, :g.patch_k] = w
+        self.patch_w = _bf(wp, d)
+        self.cls = _bf(sd[f"{V_PRE}.embeddings.class_embedding"], d)
+        self.pos = _bf(sd[f"{V_PRE}.embeddings.position_embedding.weight"], d)
+        self.pre_ln = (_bf(sd[f"{V_PRE}.pre_layrnorm.weight"], d), _bf(sd[f"{V_PRE}.pre_layrnorm.bias"], d))
+        self.vit = []
+        for i in range(g.vit_layers_run):
+            p = f"{V_PRE}.encoder.layers.{i}"
+            a = f"{p}.self_attn"
+            self.vit.append(dict(
+                ln1=(_bf(sd[f"{p}.layer_norm1.weight"], d), _bf(sd[f"{p}.layer_norm1.bias"], d)),
+                ln2=(_bf(sd[f"{p}.layer_norm2.weight"], d), _bf(sd[f"{p}.layer_norm2.bias"], d)),
+                wqkv=_bf(torch.cat([sd[f"{a}.q_proj.weight"], sd[f"{a}.k_proj.weight"], sd[f"{a}.v_proj.weight"]], 0), d),
+                bqkv=_bf(torch.cat([sd[f"{a}.q_proj.bias"], sd[f"{a}.k_proj.bias"], sd[f"{a}.v_proj.bias"]], 0), d),
+                wo=_bf(sd[f"{a}.out_proj.weight"], d), bo=_bf(sd[f"{a}.out_proj.bias"], d),
+                w1=_bf(sd[f"{p}.mlp.fc1.weight"], d), b1=_bf(sd[f"{p}.mlp.fc1.bias"], d),
+                w2=_bf(sd[f"{p}.mlp.fc2.weight"], d), b2=_bf(sd[f"{p}.mlp.fc2.bias"], d)))
+        # ---- STC connector
+        def stage(prefix):
+            blocks = []
+            for b in range(g.proj_depth):
+                q = f"{prefix}.b{b + 1}"
+                blk = dict(
+                    conv1=_bf(sd[f"{q}.conv1.conv.weight"].flatten(1), d),
+                    bn1=(_bf(sd[f"{q}.conv1.bn.weight"], d), _bf(sd[f"{q}.conv1.bn.bias"], d)),
+                    dw=_bf(sd[f"{q}.conv2.conv.weight"].flatten(1).t(), d),          # [9, C] tap-major
+                    bn2=(_bf(sd[f"{q}.conv2.bn.weight"], d), _bf(sd[f"{q}.conv2.bn.bias"], d)),
+                    se1=_bf(sd[f"{q}.se.fc1.weight"].flatten(1), d), se1b=_bf(sd[f"{q}.se.fc1.bias"], d),
+                    se2=_bf(sd[f"{q}.se.fc2.weight"].flatten(1), d), se2b=_bf(sd[f"{q}.se.fc2.bias"], d),
+                    conv3=_bf(sd[f"{q}.conv3.conv.weight"].flatten(1), d),
+                    bn3=(_bf(sd[f"{q}.conv3.bn.weight"], d), _bf(sd[f"{q}.conv3.bn.bias"], d)))
+                if f"{q}.downsample.conv.weight" in sd:
+                    blk["ds"] = _bf(sd[f"{q}.downsample.conv.weight"].flatten(1), d)
+                    blk["dsbn"] = (_bf(sd[f"{q}.downsample.bn.weight"], d), _bf(sd[f"{q}.downsample.bn.bias"], d))
+                blocks.append(blk)
+            return blocks
+        self.s1 = stage(f"{M_PRE}.s1")
+        self.s2 = stage(f"{M_PRE}.s2")
+        sw = sd[f"{M_PRE}.sampler.0.weight"]                                        # [Co, Ci, 2,2,2]
+        self.sampler_w = _bf(sw.permute(0, 2, 3, 4, 1).reshape(sw.shape[0], -1), d)  # [(kt,kh,kw,ci)] taps
+        self.sampler_b = _bf(sd[f"{M_PRE}.sampler.0.bias"], d)
+        self.ro0 = (_bf(sd[f"{M_PRE}.readout.0.weight"], d), _bf(sd[f"{M_PRE}.readout.0.bias"], d))
+        self.ro2 = (_bf(sd[f"{M_PRE}.readout.2.weight"], d), _bf(sd[f"{M_PRE}.readout.2.bias"], d))
+        # ---- decoder
+        self.embed = _bf(sd["model.embed_tokens.weight"], d)
+        self.layers = []
+        for i in range(g.layers):
+            p = f"model.layers.{i}"
+            lw = dict(
+                in_norm=_bf(sd[f"{p}.input_layernorm.weight"], d),
+                post_norm=_bf(sd[f"{p}.post_attention_layernorm.weight"], d),
+                wqkv=_bf(torch.cat([sd[f"{p}.self_attn.q_proj.weight"], sd[f"{p}.self_attn.k_proj.weight"],
+                                    sd[f"{p}.self_attn.v_proj.weight"]], 0), d),
+                wo=_bf(sd[f"{p}.self_attn.o_proj.weight"], d),
+                wgu=_bf(torch.cat([sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"]], 0), d),
+                wdown=_bf(sd[f"{p}.mlp.down_proj.weight"], d))
+            if keep_transposed:
+                for k in ("wqkv", "wo", "wgu", "wdown"):
+                    lw[k + "_t"] = ops.transpose(lw[k])
+            self.layers.append(lw)
+        self.final_norm = _bf(sd["model.norm.weight"], d)
+        inv = 1.0 / (g.rope_theta ** (torch.arange(0, g.head_dim, 2, dtype=torch.float32) / g.head_dim))
+        fr = torch.arange(g.max_len, dtype=torch.float32)[:, None] * inv[None]
+        self.rope_cos = fr.cos().to(d).contiguous()      # [S, D/2] fp32
+        self.rope_sin = fr.sin().to(d).contiguous()
+
+    @staticmethod
+    def random_state_dict(g: Geometry, device, seed: int = 1234, dtype=BF16) -> dict:
+        """Random-init weights of the real architecture directly on the device (no checkpoint is
+        reachable offline): std-0.02 linears, unit norms, fan-in scaled connector convs."""
+        gen = torch.Generator(device=device).manual_seed(seed)
+
+        def rn(*shape, std=0.02):
+            return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * std).to(dtype)
+
+        def ones(n):
+            return torch.ones(n, device=device, dtype=dtype)
+
+        def zeros(n):
+            return torch.zeros(n, device=device, dtype=dtype)
+        sd = {}
+        sd[f"{V_PRE}.embeddings.class_embedding"] = rn(g.vit_dim)
+        sd[f"{V_PRE}.embeddings.patch_embedding.weight"] = rn(g.vit_dim, 3, g.patch, g.patch)
+        sd[f"{V_PRE}.embeddings.position_embedding.weight"] = rn(g.grid * g.grid + 1, g.vit_dim)
+        sd[f"{V_PRE}.pre_layrnorm.weight"] = ones(g.vit_dim)
+        sd[f"{V_PRE}.pre_layrnorm.bias"] = zeros(g.vit_dim)
+        for i in range(g.vit_layers):
+            p = f"{V_PRE}.encoder.layers.{i}"
+            for ln in ("layer_norm1", "layer_norm2"):
+                sd[f"{p}.{ln}.weight"] = ones(g.vit_dim)
+                sd[f"{p}.{ln}.bias"] = zeros(g.vit_dim)
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[f"{p}.self_attn.{n}.weight"] = rn(g.vit_dim, g.vit_dim)
+                sd[f"{p}.self_attn.{n}.bias"] = zeros(g.vit_dim)
+            sd[f"{p}.mlp.fc1.weight"] = rn(g.vit_ff, g.vit_dim)
+            sd[f"{p}.mlp.fc1.bias"] = zeros(g.vit_ff)
+            sd[f"{p}.mlp.fc2.weight"] = rn(g.vit_dim, g.vit_ff)
+            sd[f"{p}.mlp.fc2.bias"] = zeros(g.vit_dim)
+        for st, cin in (("s1", g.vit_dim), ("s2", g.dim)):
+            for b in range(g.proj_depth):
+                ci = cin if b == 0 else g.dim
+                q = f"{M_PRE}.{st}.b{b + 1}"
+                rd = int(round(ci * g.proj_se_ratio))
+                sd[f"{q}.conv1.conv.weight"] = rn(g.dim, ci, 1, 1, std=1 / math.sqrt(ci))
+                sd[f"{q}.conv2.conv.weight"] = rn(g.dim, 1, 3, 3, std=1 / 3)
+                sd[f"{q}.se.fc1.weight"] = rn(rd, g.dim, 1, 1, std=1 / math.sqrt(g.dim))
+                sd[f"{q}.se.fc1.bias"] = zeros(rd)
+                sd[f"{q}.se.fc2.weight"] = rn(g.dim, rd, 1, 1, std=1 / math.sqrt(rd))
+                sd[f"{q}.se.fc2.bias"] = zeros(g.dim)
+                sd[f"{q}.conv3.conv.weight"] = rn(g.dim, g.dim, 1, 1, std=1 / math.sqrt(g.dim))
+                for n in ("conv1", "conv2", "conv3"):
+                    sd[f"{q}.{n}.bn.weight"] = ones(g.dim)
+                    sd[f"{q}.{n}.bn.bias"] = zeros(g.dim)
+                if ci != g.dim:
+                    sd[f"{q}.downsample.conv.weight"] = rn(g.dim, ci, 1, 1, std=1 / math.sqrt(ci))
+                    sd[f"{q}.downsample.bn.weight"] = ones(g.dim)
+                    sd[f"{q}.downsample.bn.bias"] = zeros(g.dim)
+        sd[f"{M_PRE}.sampler.0.weight"] = rn(g.dim, g.dim, 2, 2, 2, std=1 / math.sqrt(8 * g.dim))
+        sd[f"{M_PRE}.sampler.0.bias"] = zeros(g.dim)
+        for n in ("readout.0", "readout.2"):
+            sd[f"{M_PRE}.{n}.weight"] = rn(g.dim, g.dim, std=1 / math.sqrt(g.dim))
+            sd[f"{M_PRE}.{n}.bias"] = zeros(g.dim)
+        sd["model.embed_tokens.weight"] = rn(g.vocab, g.dim)
+        for i in range(g.layers):
+            p = f"model.layers.{i}"
+            sd[f"{p}.self_attn.q_proj.weight"] = rn(g.heads * g.head_dim, g.dim)
+            sd[f"{p}.self_attn.k_proj.weight"] = rn(g.kv_heads * g.head_dim, g.dim)
+            sd[f"{p}.self_attn.v_proj.weight"] = rn(g.kv_heads * g.head_dim, g.dim)
+            sd[f"{p}.self_attn.o_proj.weight"] = rn(g.dim, g.heads * g.head_dim)
+            sd[f"{p}.mlp.gate_proj.weight"] = rn(g.ff, g.dim)
+            sd[f"{p}.mlp.up_proj.weight"] = rn(g.ff, g.dim)
+            sd[f"{p}.mlp.down_proj.weight"] = rn(g.dim, g.ff)
+            sd[f"{p}.input_layernorm.weight"] = ones(g.dim)
+            sd[f"{p}.post_attention_layernorm.weight"] = ones(g.dim)
+        sd["model.norm.weight"] = ones(g.dim)
+        return sd
+
+
+class Backbone:
+    """Forward of the frozen VideoLLaMA2 stack on libvlb kernels."""
+
+    def __init__(self, g: Geometry, weights: Weights):
+        self.g = g
+        self.w = weights
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=weights.dev)
+
+    # ---------------- a4: CLIP tower (transformers modeling_clip.py:138-219,280-384)
+    def vision_tower(self, vision_f32):
+        """vision fp32 [N,3,H,W] -> patch features bf16 [N*grid^2, vit_dim] of hidden_states[-2]."""
+        g, w = self.g, self.w
+        N = vision_f32.shape[0]
+        G, T = g.grid * g.grid, g.grid * g.grid + 1
+        hd = g.vit_dim // g.vit_heads
+        patches = ops.patchify(vision_f32, g.patch, g.patch_k_padded)
+        pe = ops.gemm(patches, w.patch_w)
+        x = ops.vit_assemble(pe, w.cls, w.pos, N, G, g.vit_dim)
+        x = ops.layernorm(x, *w.pre_ln, g.vit_eps)
+        D = g.vit_dim
+        for lw in w.vit:
+            h = ops.layernorm(x, *lw["ln1"], g.vit_eps)
+            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])
+            a = ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], N, T, g.vit_heads, g.vit_heads, hd,
+                                  False, hd ** -0.5)
+            x = ops.gemm(a, lw["wo"], bias=lw["bo"], residual=x)
+            h = ops.layernorm(x, *lw["ln2"], g.vit_eps)
+            h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_QUICK_GELU)
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], residual=x)
+        return ops.drop_cls(x, N, G, D)
+
+    # ---------------- a5: STC connector (VideoLLaMA2 projector + timm RegStage)
+    def _bottleneck(self, x, blk, N, H):
+        g = self.g
+        C = g.dim
+        y = ops.gemm(x, blk["conv1"])
+        y = ops.layernorm(y, *blk["bn1"], g.proj_eps, act=ops.ACT_SILU)
+        y = ops.dwconv3x3(y, blk["dw"], N, H, H, C)
+        y = ops.layernorm(y, *blk["bn2"], g.proj_eps, act=ops.ACT_SILU)
+        s = ops.se_pool(y, N, H * H, C)
+        s = ops.gemm(s, blk["se1"], bias=blk["se1b"], act=ops.ACT_SILU)
+        s = ops.gemm(s, blk["se2"], bias=blk["se2b"])
+        y = ops.se_scale(y, s, N, H * H, C, out=y)
+        y = ops.gemm(y, blk["conv3"])
+        sc = x
+        if "ds" in blk:
+            sc = ops.layernorm(ops.gemm(x, blk["ds"]), *blk["dsbn"], g.proj_eps)
+        return ops.layernorm(y, *blk["bn3"], g.proj_eps, residual=sc, act=ops.ACT_SILU)
+
+    def connector(self, feats, B):
+        """feats bf16 [B*T*grid^2, vit_dim] -> video tokens bf16 [B*vis_tokens, dim]."""
+        g, w = self.g, self.w
+        x = feats
+        for blk in w.s1:
+            x = self._bottleneck(x, blk, B * g.num_frames, g.grid)
+        cols = ops.im2col3d(x, B, g.num_frames, g.grid, g.grid, g.dim)
+        x = ops.gemm(cols, w.sampler_w, bias=w.sampler_b, act=ops.ACT_SILU)
+        for blk in w.s2:
+            x = self._bottleneck(x, blk, B * g.ds_frames, g.ds_grid)
+        x = ops.gemm(x, w.ro0[0], bias=w.ro0[1], act=ops.ACT_GELU)
+        return ops.gemm(x, w.ro2[0], bias=w.ro2[1])
+
+    # ---------------- a7: one Mistral decoder layer (modeling_mistral.py:202-240)
+    def decoder_layer(self, x, lw, key_mask, B, S, save=None):
+        g = self.g
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        h = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
+        qkv = ops.gemm(h, lw["wqkv"])
+        ops.rope_(qkv, self.w.rope_cos, self.w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim)
+        a = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads, g.head_dim,
+                              True, g.head_dim ** -0.5, key_mask=key_mask)
+        x = ops.gemm(a, lw["wo"], residual=x)
+        h = ops.rmsnorm(x, lw["post_norm"], g.rms_eps)
+        gu = ops.gemm(h, lw["wgu"])
+        h = ops.swiglu(gu)
+        return ops.gemm(h, lw["wdown"], residual=x)
+
+    def splice(self, ids, video_tokens):
+        g = self.g
+        return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag)
+
+    def decoder(self, x, key_mask, B, S, layer_outputs=None):
+        for lw in self.w.layers:
+            x = self.decoder_layer(x, lw, key_mask, B, S)
+            if layer_outputs is not None:
+                layer_outputs.append(x)
+        return ops.rmsnorm(x, self.w.final_norm, self.g.rms_eps)
+
+    def forward(self, vision_f32, ids, stages=None):
+        """vision fp32 [B,T,3,H,W], ids int64 [B,L] -> hidden bf16 [B*S, dim], key_mask uint8 [B,S]."""
+        g = self.g
+        B = vision_f32.shape[0]
+        pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
+        feats = self.vision_tower(pix)
+        vid = self.connector(feats, B)
+        emb, key_mask = self.splice(ids, vid)
+        louts = [] if stages is not None else None
+        hidden = self.decoder(emb, key_mask, B, g.max_len, louts)
+        if stages is not None:
+            stages.update(vit_tokens=feats, video_tokens=vid, inputs_embeds=emb, key_mask=key_mask,
+                          layer_outputs=louts, hidden=hidden)
+        return hidden, key_mask

@@ -1,0 +1,360 @@
+// bf16 MFMA GEMMs for gfx950:  C[M,N] = act(A[M,K].W[N,K]^T + A2.W2^T + bias) + residual
+//
+// Two kernels:
+//  * gemm_tile_kernel<BM,BN,WM,WN>: 512 threads (8 waves), BK=64, LDS-DMA staging
+//    (global_load_lds_dwordx4, swizzle applied on the SOURCE address), double-buffered LDS,
+//    v_mfma_f32_16x16x32_bf16, XCD-aware tile order.  Needs N % BN == 0, K % 64 == 0; any M.
+//  * gemm_generic_kernel: 64x64 tile, bounds-checked register staging, any M/N, K % 8 == 0.
+//
+// MFMA operand roles are swapped on purpose (rows of the MFMA = output COLUMNS n, columns of the
+// MFMA = output rows m): each lane then owns 4 consecutive n of one row m per 16x16 tile, so the
+// epilogue packs 4 bf16 into one 8-byte store and bias/residual are 8-byte loads.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BK = 64;           // K elements per LDS tile row (128 bytes)
+constexpr int ROW_BYTES = BK * 2;
+
+struct GemmArgs {
+  const bf16* A;  const bf16* W;  bf16* C;
+  const bf16* A2; const bf16* W2;
+  const bf16* bias; const bf16* residual;
+  int M, N, K, K2;
+  int lda, ldw, ldc, ldr, lda2, ldw2;
+  int act;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case VLB_ACT_QUICK_GELU: return quick_gelu_f(x);
+    case VLB_ACT_GELU: return gelu_erf_f(x);
+    case VLB_ACT_SILU: return silu_f(x);
+    default: return x;
+  }
+}
+
+// LDS image of a [rows][64] bf16 tile: 128-byte rows, 16-byte chunk c of row r lives at slot
+// c ^ ((r>>1)&7).  Two rows share one 256-byte bank row, so the 16 rows x 1 chunk column that a
+// ds_read_b128 lane group touches land on 16 distinct 16-byte slots: conflict-free.
+__device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                   (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int TM = BM / WM, TN = BN / WN;   // per-wave output tile
+  constexpr int MT = TM / 16, NT = TN / 16;   // 16x16 MFMA tiles per wave
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LD = BM / 64, B_LD = BN / 64;  // glds instructions per thread per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile order: blocks b and b+8 share an XCD, give each XCD a contiguous run of
+  // tiles, walked in bands of GROUP_M row-tiles so concurrently resident tiles share A/W panels in L2.
+  const int nblk = p.tiles_m * p.tiles_n;
+  int pid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
+    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  constexpr int GROUP_M = 4;
+  const int band = GROUP_M * p.tiles_n;
+  const int g0 = (pid / band) * GROUP_M;
+  const int gsz = min(p.tiles_m - g0, GROUP_M);
+  const int tm = g0 + (pid % band) % gsz;
+  const int tn = (pid % band) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- staging addresses: instruction i of this wave fills LDS rows [i*64 + wave*8, +8)
+  const int srow = (lane >> 3), sslot = lane & 7;
+  const bf16* a_src[A_LD]; const bf16* b_src[B_LD];
+  const bf16* a2_src[A_LD]; const bf16* b2_src[B_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int r = i * 64 + wave * 8 + srow;
+    const int c = sslot ^ ((r >> 1) & 7);
+    const int gm = min(m0 + r, p.M - 1);
+    a_src[i] = p.A + (int64_t)gm * p.lda + c * 8;
+    a2_src[i] = p.A2 ? p.A2 + (int64_t)gm * p.lda2 + c * 8 : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int r = i * 64 + wave * 8 + srow;
+    const int c = sslot ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (int64_t)(n0 + r) * p.ldw + c * 8;
+    b2_src[i] = p.W2 ? p.W2 + (int64_t)(n0 + r) * p.ldw2 + c * 8 : nullptr;
+  }
+  const int nk1 = p.K / BK;
+  const int nk = nk1 + p.K2 / BK;
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE + wave * 8 * ROW_BYTES;
+    if (kt < nk1) {
+      const int ko = kt * BK;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) glds16(a_src[i] + ko, base + i * 64 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) glds16(b_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
+    } else {
+      const int ko = (kt - nk1) * BK;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) glds16(a2_src[i] + ko, base + i * 64 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) glds16(b2_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (within a stage): row = tile_row0 + (lane&15), chunk = ks*4 + (lane>>4)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[MT][2], b_off[NT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = lds_off(wm * TM + i * 16 + fr, ks * 4 + fq);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = A_BYTES + lds_off(wn * TN + j * 16 + fr, ks * 4 + fq);
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sb = smem + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[MT], wf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i][ks]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns n = nbase + fq*4 + {0..3} of row m = mbase + fr, per 16x16 tile
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * TM + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + fq * 4;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+      }
+      if (p.act != VLB_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      if (p.residual) {
+        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic bounds-checked kernel: 64x64 tile, 256 threads (2x2 waves, each 32x32 = 2x2 MFMA tiles),
+// BK = 32, register staging into padded LDS rows.  Correct for every shape with K % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int GK = 32;
+constexpr int GLD = GK + 8;   // padded row (80 bytes): 16-byte aligned, breaks power-of-two stride
+
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16 sA[64 * GLD];
+  __shared__ __attribute__((aligned(16))) bf16 sW[64 * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  // each thread stages one 16-byte chunk of A and one of W per k-tile: row = tid/4, chunk = tid%4
+  const int lr = tid >> 2, lc = tid & 3;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const bf16* A = pass ? p.A2 : p.A;
+    const bf16* W = pass ? p.W2 : p.W;
+    const int K = pass ? p.K2 : p.K;
+    const int lda = pass ? p.lda2 : p.lda, ldw = pass ? p.ldw2 : p.ldw;
+    if (K == 0 || A == nullptr) continue;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+      bf16x8 va = {}, vw = {};
+      const int kk = k0 + lc * 8;
+      if (m0 + lr < p.M && kk < K) va = *reinterpret_cast<const bf16x8*>(A + (int64_t)(m0 + lr) * lda + kk);
+      if (n0 + lr < p.N && kk < K) vw = *reinterpret_cast<const bf16x8*>(W + (int64_t)(n0 + lr) * ldw + kk);
+      __syncthreads();
+      *reinterpret_cast<bf16x8*>(&sA[lr * GLD + lc * 8]) = va;
+      *reinterpret_cast<bf16x8*>(&sW[lr * GLD + lc * 8]) = vw;
+      __syncthreads();
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&sA[(wm * 32 + i * 16 + fr) * GLD + fq * 8]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&sW[(wn * 32 + j * 16 + fr) * GLD + fq * 8]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nb = n0 + wn * 32 + j * 16 + fq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nb + e;
+        if (n >= p.N) continue;
+        float v = acc[i][j][e];
+        if (p.bias) v += (float)p.bias[n];
+        v = apply_act(v, p.act);
+        if (p.residual) v += (float)p.residual[(int64_t)m * p.ldr + n];
+        p.C[(int64_t)m * p.ldc + n] = (bf16)v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_tile(GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+      return VLB_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = a.N / BN;
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+// 16x16 LDS-tiled transpose, 32x32 elements per block
+__global__ void transpose_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int R, int C) {
+  __shared__ bf16 t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < R && c < C) t[i][threadIdx.x] = in[(int64_t)r * C + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) out[(int64_t)c * R + r] = t[threadIdx.x][i];
+  }
+}
+
+}  // namespace
+
+// Tile choice exported for tests / DESIGN.md: 0 generic, 1 = 256x256, 2 = 256x128
+extern "C" int vlb_gemm_kernel_choice(int M, int N, int K, int K2) {
+  if (K % BK != 0 || K2 % BK != 0 || K == 0 || M < 128) return 0;
+  const int cus = 256;
+  if (N % 256 == 0) {
+    const int t256 = ((M + 255) / 256) * (N / 256);
+    // prefer the bigger tile unless it leaves the last wave of tiles mostly empty
+    if (N % 128 == 0) {
+      const int t128 = ((M + 255) / 256) * (N / 128);
+      const float e256 = (float)t256 / (float)(((t256 + cus - 1) / cus) * cus);
+      const float e128 = (float)t128 / (float)(((t128 + cus - 1) / cus) * cus);
+      if (e128 > e256 + 0.08f) return 2;
+    }
+    return 1;
+  }
+  if (N % 128 == 0) return 2;
+  return 0;
+}
+
+extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                             const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                             const void* W2, int ldw2, int K2, void* stream) {
+  VLB_REQUIRE(A && W && C, "gemm: null operand");
+  VLB_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  VLB_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
+  VLB_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than row");
+  if (K2 > 0) {
+    VLB_REQUIRE(A2 && W2, "gemm: K2>0 needs A2 and W2");
+    VLB_REQUIRE(K2 % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && lda2 >= K2 && ldw2 >= K2, "gemm: bad second operand pair");
+  } else {
+    A2 = nullptr; W2 = nullptr; K2 = 0;
+  }
+  if (residual) VLB_REQUIRE(ldr >= N, "gemm: ldr < N");
+  GemmArgs a;
+  a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = (bf16*)C;
+  a.A2 = (const bf16*)A2; a.W2 = (const bf16*)W2;
+  a.bias = (const bf16*)bias; a.residual = (const bf16*)residual;
+  a.M = M; a.N = N; a.K = K; a.K2 = K2;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
+  a.act = act; a.tiles_m = 0; a.tiles_n = 0;
+  hipStream_t s = as_stream(stream);
+  const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
+                      (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
+                      (((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2) % 16 == 0);
+  const int choice = vec_ok ? vlb_gemm_kernel_choice(M, N, K, K2) : 0;
+  if (choice == 1) return launch_tile<256, 256, 2, 4>(a, s);
+  if (choice == 2) return launch_tile<256, 128, 4, 2>(a, s);
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {
+  VLB_REQUIRE(in && out && R > 0 && C > 0, "transpose: bad args");
+  dim3 grid((C + 31) / 32, (R + 31) / 32), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, as_stream(stream), (const bf16*)in, (bf16*)out, R, C);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}

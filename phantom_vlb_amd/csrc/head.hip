@@ -1,0 +1,466 @@
+// Fused brain head (the arithmetic the reference itself owns):
+//   hidden --LN1--> sum_s w[b,s]*(.) --LN2--> dropout --Linear(E->V)--> pred ; loss = MSE + lambda*||W||^2
+// reference: src/litmodule/videollama2_vlb_litmodule.py:245-254,302 ; src/utils.py:56,66-71.
+//
+// HBM-bound.  The LN1-normalised [B,S,E] tensor is never materialised: because LN1's affine is
+// per-column,   pooled[e] = g1[e] * sum_s w_s*rstd_s*(x_se - mu_s) + b1[e] * sum_s w_s,
+// so one pass over `hidden` with per-token (mu, rstd) suffices, and tokens whose HRF weight is zero
+// (the prompt, instruction and padding spans) are skipped altogether.
+// All cross-block reductions go through partial slabs summed in a fixed order (bitwise reproducible).
+#include "common.hpp"
+
+namespace {
+
+constexpr int POOL_ROWS = 32;     // tokens per pooling block (8 waves x 4 tokens)
+constexpr int RIDGE_ROWS = 8;     // ridge rows per block (4 waves x 2 rows)
+constexpr int BMAX = 8;           // clips handled per pass by the ridge kernels
+constexpr int DZ_SPLIT = 32;      // V-splits of the dz reduction
+
+__device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+
+// ---------------------------------------------------------------- forward 1: LN1 stats + weighted pool
+template <int NI>   // NI = ceil(E/512) chunks of 8 columns per lane
+__global__ __launch_bounds__(512) void head_pool_kernel(const bf16* __restrict__ hidden, const float* __restrict__ wmask,
+                                                        float* __restrict__ partial, float* __restrict__ stats, int S,
+                                                        int E, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][E]
+  const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[NI][8];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  float sw = 0.f;
+  for (int r = wave; r < POOL_ROWS; r += 8) {
+    const int s = blk * POOL_ROWS + r;
+    if (s >= S) break;
+    const float w = wmask[(int64_t)b * S + s];
+    if (w == 0.f) continue;                       // wave-uniform: contributes nothing forward or backward
+    const bf16* xr = hidden + ((int64_t)b * S + s) * E;
+    float x[NI][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < E) ld8(xr + c, x[i]); else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += x[i][j];
+    }
+    const float mu = wave_sum(sum) / E;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < E) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = x[i][j] - mu; var += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(var) / E + eps);
+    const float a = w * rstd;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] += a * (x[i][j] - mu);
+    sw += w;
+    if (lane == 0) { stats[((int64_t)b * S + s) * 2] = mu; stats[((int64_t)b * S + s) * 2 + 1] = rstd; }
+  }
+  // deterministic tree reduction over the 8 waves through LDS
+  for (int stride = 4; stride >= 1; stride >>= 1) {
+    if (wave >= stride && wave < 2 * stride) {
+      float* dst = red + (wave - stride) * E;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < E) {
+          *reinterpret_cast<f32x4*>(dst + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+          *reinterpret_cast<f32x4*>(dst + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        }
+      }
+      if (lane == 0) red[4 * E + (wave - stride)] = sw;
+    }
+    __syncthreads();
+    if (wave < stride) {
+      const float* src = red + wave * E;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane * 8 + i * 512;
+        if (c < E) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src + c), hi = *reinterpret_cast<const f32x4*>(src + c + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[i][j] += lo[j]; acc[i][4 + j] += hi[j]; }
+        }
+      }
+      sw += red[4 * E + wave];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float* dst = partial + ((int64_t)b * nblk + blk) * (E + 2);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + i * 512;
+      if (c < E) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[c + j] = acc[i][j];
+      }
+    }
+    if (lane == 0) dst[E] = sw;
+  }
+}
+
+// ---------------------------------------------------------------- forward 2: finish pool, LN1 affine, LN2, dropout
+__global__ __launch_bounds__(1024) void head_finish_kernel(const float* __restrict__ partial, int nblk,
+                                                           const bf16* __restrict__ g1, const bf16* __restrict__ b1,
+                                                           const bf16* __restrict__ g2, const bf16* __restrict__ b2,
+                                                           const float* __restrict__ keep, float* __restrict__ pooled_raw,
+                                                           float* __restrict__ sumw, float* __restrict__ zhat,
+                                                           float* __restrict__ ln2_rstd, bf16* __restrict__ z, int E,
+                                                           float eps) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const float* pb = partial + (int64_t)b * nblk * (E + 2);
+  float sw = 0.f;
+  for (int k = 0; k < nblk; ++k) sw += pb[(int64_t)k * (E + 2) + E];
+  float lsum = 0.f;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float raw = 0.f;
+    for (int k = 0; k < nblk; ++k) raw += pb[(int64_t)k * (E + 2) + e];
+    pooled_raw[(int64_t)b * E + e] = raw;
+    lsum += (float)g1[e] * raw + (float)b1[e] * sw;
+  }
+  const float mean = block_sum(lsum, red) / E;
+  float lvar = 0.f;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    const float pv = (float)g1[e] * pooled_raw[(int64_t)b * E + e] + (float)b1[e] * sw;
+    lvar += (pv - mean) * (pv - mean);
+  }
+  const float rstd = rsqrtf(block_sum(lvar, red) / E + eps);
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    const float pv = (float)g1[e] * pooled_raw[(int64_t)b * E + e] + (float)b1[e] * sw;
+    const float zh = (pv - mean) * rstd;
+    zhat[(int64_t)b * E + e] = zh;
+    float zz = zh * (float)g2[e] + (float)b2[e];
+    if (keep) zz *= keep[(int64_t)b * E + e];
+    z[(int64_t)b * E + e] = (bf16)zz;
+  }
+  if (threadIdx.x == 0) { sumw[b] = sw; ln2_rstd[b] = rstd; }
+}
+
+// ---------------------------------------------------------------- forward 3: ridge GEMV + loss partials
+// block = 4 waves, each wave 2 rows of W; z (bf16, [B,E]) is read through L1/L2 (B*E*2 bytes, shared by all).
+__global__ __launch_bounds__(256) void ridge_fwd_kernel(const bf16* __restrict__ W, const bf16* __restrict__ bias,
+                                                        const bf16* __restrict__ z, const float* __restrict__ y,
+                                                        float* __restrict__ pred, float* __restrict__ lpart, int B, int E,
+                                                        int V) {
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mse = 0.f, w2 = 0.f;
+  for (int rr = 0; rr < RIDGE_ROWS / 4; ++rr) {
+    const int v = blockIdx.x * RIDGE_ROWS + wave * (RIDGE_ROWS / 4) + rr;
+    if (v >= V) break;
+    const bf16* wr = W + (int64_t)v * E;
+    for (int b0 = 0; b0 < B; b0 += BMAX) {
+      const int nb = min(BMAX, B - b0);
+      float acc[BMAX];
+#pragma unroll
+      for (int i = 0; i < BMAX; ++i) acc[i] = 0.f;
+      for (int c = lane * 8; c < E; c += 512) {
+        float w[8]; ld8(wr + c, w);
+        if (b0 == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w2 += w[j] * w[j];
+        }
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) {
+          if (i < nb) {
+            float zz[8]; ld8(z + (int64_t)(b0 + i) * E + c, zz);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i] += w[j] * zz[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BMAX; ++i) {
+        if (i < nb) {
+          const float pv = wave_sum(acc[i]) + (float)bias[v];
+          if (lane == 0) {
+            pred[(int64_t)(b0 + i) * V + v] = pv;
+            const float d = pv - y[(int64_t)(b0 + i) * V + v];
+            mse += d * d;
+          }
+        }
+      }
+    }
+  }
+  w2 = wave_sum(w2);
+  if (lane == 0) { red[wave] = mse; red[4 + wave] = w2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lpart[blockIdx.x * 2] = red[0] + red[1] + red[2] + red[3];
+    lpart[blockIdx.x * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+__global__ void loss_finalize_kernel(const float* __restrict__ lpart, int nblk, float inv_bv, float lambda,
+                                     float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double mse = 0.0, w2 = 0.0;
+    for (int i = 0; i < nblk; ++i) { mse += lpart[2 * i]; w2 += lpart[2 * i + 1]; }
+    out[0] = (float)(mse * inv_bv);
+    out[1] = (float)(lambda * w2);
+    out[2] = out[0] + out[1];
+  }
+}
+
+// ---------------------------------------------------------------- backward 1: dW, dbias
+__global__ __launch_bounds__(256) void ridge_bwd_w_kernel(const bf16* __restrict__ W, const bf16* __restrict__ z,
+                                                          const float* __restrict__ pred, const float* __restrict__ y,
+                                                          float* __restrict__ dW, float* __restrict__ dbias, int B, int E,
+                                                          int V, float gscale, float l2coef) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < RIDGE_ROWS / 4; ++rr) {
+    const int v = blockIdx.x * RIDGE_ROWS + wave * (RIDGE_ROWS / 4) + rr;
+    if (v >= V) break;
+    float db = 0.f;
+    for (int b = 0; b < B; ++b) db += gscale * (pred[(int64_t)b * V + v] - y[(int64_t)b * V + v]);
+    if (lane == 0) dbias[v] = db;
+    const bf16* wr = W + (int64_t)v * E;
+    for (int c = lane * 8; c < E; c += 512) {
+      float w[8], g[8]; ld8(wr + c, w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = l2coef * w[j];
+      for (int b = 0; b < B; ++b) {
+        const float dp = gscale * (pred[(int64_t)b * V + v] - y[(int64_t)b * V + v]);
+        float zz[8]; ld8(z + (int64_t)b * E + c, zz);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += dp * zz[j];
+      }
+      float* o = dW + (int64_t)v * E + c;
+      *reinterpret_cast<f32x4*>(o) = f32x4{g[0], g[1], g[2], g[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{g[4], g[5], g[6], g[7]};
+    }
+  }
+}
+// ---------------------------------------------------------------- backward 2: dz partials over V splits
+// grid (ceil(E/512), DZ_SPLIT), block 256 (4 waves share a split's rows); out part[split][B][E]
+__global__ __launch_bounds__(256) void ridge_bwd_z_kernel(const bf16* __restrict__ W, const float* __restrict__ pred,
+                                                          const float* __restrict__ y, float* __restrict__ part, int B,
+                                                          int E, int V, float gscale) {
+  __shared__ float red[3][BMAX][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  const int per = (V + DZ_SPLIT - 1) / DZ_SPLIT;
+  const int v0 = blockIdx.y * per, v1 = min(V, v0 + per);
+  for (int b0 = 0; b0 < B; b0 += BMAX) {
+    const int nb = min(BMAX, B - b0);
+    float acc[BMAX][8];
+#pragma unroll
+    for (int i = 0; i < BMAX; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    if (c < E) {
+      for (int v = v0 + wave; v < v1; v += 4) {
+        float w[8]; ld8(W + (int64_t)v * E + c, w);
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) {
+          if (i < nb) {
+            const float dp = gscale * (pred[(int64_t)(b0 + i) * V + v] - y[(int64_t)(b0 + i) * V + v]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] += dp * w[j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < BMAX; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave - 1][i][lane * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (wave == 0 && c < E) {
+#pragma unroll
+      for (int i = 0; i < BMAX; ++i) {
+        if (i < nb) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            part[((int64_t)blockIdx.y * B + b0 + i) * E + c + j] =
+                acc[i][j] + red[0][i][lane * 8 + j] + red[1][i][lane * 8 + j] + red[2][i][lane * 8 + j];
+        }
+      }
+    }
+  }
+}
+// ---------------------------------------------------------------- backward 3: dropout, LN2, LN1-affine grads
+__global__ __launch_bounds__(1024) void head_bwd_finish_kernel(const float* __restrict__ part, const bf16* __restrict__ g1,
+                                                               const bf16* __restrict__ g2, const float* __restrict__ keep,
+                                                               const float* __restrict__ pooled_raw,
+                                                               const float* __restrict__ sumw, const float* __restrict__ zhat,
+                                                               const float* __restrict__ ln2_rstd, float* __restrict__ dg2,
+                                                               float* __restrict__ db2, float* __restrict__ dg1,
+                                                               float* __restrict__ db1, float* __restrict__ dz,
+                                                               float* __restrict__ draw, int B, int E) {
+  __shared__ float red[16];
+  for (int e = threadIdx.x; e < E; e += blockDim.x) { dg2[e] = 0.f; db2[e] = 0.f; dg1[e] = 0.f; db1[e] = 0.f; }
+  for (int b = 0; b < B; ++b) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      float d = 0.f;
+      for (int k = 0; k < DZ_SPLIT; ++k) d += part[((int64_t)k * B + b) * E + e];
+      if (keep) d *= keep[(int64_t)b * E + e];
+      dz[(int64_t)b * E + e] = d;
+      const float zh = zhat[(int64_t)b * E + e];
+      dg2[e] += d * zh;
+      db2[e] += d;
+      const float g = d * (float)g2[e];
+      s1 += g; s2 += g * zh;
+    }
+    const float m1 = block_sum(s1, red) / E;
+    const float m2 = block_sum(s2, red) / E;
+    const float rstd = ln2_rstd[b], sw = sumw[b];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+      const float zh = zhat[(int64_t)b * E + e];
+      const float g = dz[(int64_t)b * E + e] * (float)g2[e];
+      const float dp = rstd * (g - m1 - zh * m2);           // d loss / d pooled[b,e]
+      dg1[e] += dp * pooled_raw[(int64_t)b * E + e];
+      db1[e] += dp * sw;
+      draw[(int64_t)b * E + e] = dp * (float)g1[e];          // d loss / d pooled_raw[b,e]
+    }
+  }
+}
+// ---------------------------------------------------------------- backward 4: d hidden (one wave per token)
+__global__ __launch_bounds__(256) void head_dhidden_kernel(const bf16* __restrict__ hidden, const float* __restrict__ wmask,
+                                                           const float* __restrict__ stats, const float* __restrict__ draw,
+                                                           bf16* __restrict__ dh, int S, int E, int64_t rows) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int64_t b = row / S;
+  const float w = wmask[row];
+  bf16* dr = dh + row * E;
+  if (w == 0.f) {
+    for (int c = lane * 8; c < E; c += 512) *reinterpret_cast<bf16x8*>(dr + c) = bf16x8{};
+    return;
+  }
+  const float mu = stats[row * 2], rstd = stats[row * 2 + 1];
+  const bf16* xr = hidden + row * E;
+  const float* u = draw + b * E;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 8; c < E; c += 512) {
+    float x[8]; ld8(xr + c, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float g = w * u[c + j]; s1 += g; s2 += g * (x[j] - mu) * rstd; }
+  }
+  const float m1 = wave_sum(s1) / E, m2 = wave_sum(s2) / E;
+  for (int c = lane * 8; c < E; c += 512) {
+    float x[8]; ld8(xr + c, x);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(rstd * (w * u[c + j] - m1 - (x[j] - mu) * rstd * m2));
+    *reinterpret_cast<bf16x8*>(dr + c) = o;
+  }
+}
+
+template <int NI>
+int launch_pool(const bf16* hidden, const float* wmask, float* partial, float* stats, int B, int S, int E, float eps,
+                hipStream_t st) {
+  const int lds = (4 * E + 8) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pool_kernel<NI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (4 * NI * 512 + 8) * (int)sizeof(float));
+    if (e != hipSuccess) { vlb_set_error("head: LDS reservation failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+    configured = true;
+  }
+  dim3 grid((S + POOL_ROWS - 1) / POOL_ROWS, B);
+  hipLaunchKernelGGL((head_pool_kernel<NI>), grid, dim3(512), lds, st, hidden, wmask, partial, stats, S, E, eps);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+}  // namespace
+
+extern "C" int vlb_head_partial_rows(int S) { return (S + POOL_ROWS - 1) / POOL_ROWS; }
+extern "C" int64_t vlb_head_ws_floats(int B, int S, int E, int V) {
+  const int64_t pool = (int64_t)B * vlb_head_partial_rows(S) * (E + 2);
+  const int64_t ridge = 2 * (int64_t)((V + RIDGE_ROWS - 1) / RIDGE_ROWS);
+  const int64_t dz = (int64_t)DZ_SPLIT * B * E;
+  int64_t m = pool + ridge;
+  return m > dz ? m : dz;
+}
+
+extern "C" int vlb_head_fwd(const void* hidden, const float* wmask, const void* ln1_w, const void* ln1_b,
+                            const void* ln2_w, const void* ln2_b, const void* ridge_w, const void* ridge_b,
+                            const float* y, const float* keep_scale, float* ws, float* stats, float* pooled_raw,
+                            float* sumw, float* zhat, float* ln2_rstd, void* z, float* pred, float* loss_terms, int B,
+                            int S, int E, int V, float eps, float l2_lambda, void* stream) {
+  VLB_REQUIRE(hidden && wmask && ln1_w && ln1_b && ln2_w && ln2_b && ridge_w && ridge_b && y && ws && stats &&
+                  pooled_raw && sumw && zhat && ln2_rstd && z && pred && loss_terms, "head_fwd: null argument");
+  VLB_REQUIRE(B > 0 && S > 0 && V > 0 && E % 8 == 0 && E > 0 && E <= 8192, "head_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
+  hipStream_t st = as_stream(stream);
+  const int nblk = vlb_head_partial_rows(S);
+  float* partial = ws;
+  float* lpart = ws + (int64_t)B * nblk * (E + 2);
+  const int ni = (E + 511) / 512;
+  int rc;
+  if (ni <= 1) rc = launch_pool<1>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  else if (ni <= 2) rc = launch_pool<2>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  else if (ni <= 4) rc = launch_pool<4>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  else if (ni <= 8) rc = launch_pool<8>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  else rc = launch_pool<16>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  if (rc != VLB_OK) return rc;
+  hipLaunchKernelGGL(head_finish_kernel, dim3(B), dim3(1024), 0, st, partial, nblk, (const bf16*)ln1_w,
+                     (const bf16*)ln1_b, (const bf16*)ln2_w, (const bf16*)ln2_b, keep_scale, pooled_raw, sumw, zhat,
+                     ln2_rstd, (bf16*)z, E, eps);
+  VLB_LAUNCH_CHECK();
+  const int rblk = (V + RIDGE_ROWS - 1) / RIDGE_ROWS;
+  hipLaunchKernelGGL(ridge_fwd_kernel, dim3(rblk), dim3(256), 0, st, (const bf16*)ridge_w, (const bf16*)ridge_b,
+                     (const bf16*)z, y, pred, lpart, B, E, V);
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, lpart, rblk, 1.f / ((float)B * (float)V),
+                     l2_lambda, loss_terms);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, const void* ln2_w,
+                            const void* ridge_w, const float* y, const float* keep_scale, const float* stats,
+                            const float* pooled_raw, const float* sumw, const float* zhat, const float* ln2_rstd,
+                            const void* z, const float* pred, float* d_ridge_w, float* d_ridge_b, float* d_ln2_w,
+                            float* d_ln2_b, float* d_ln1_w, float* d_ln1_b, float* ws, float* dz_ws, float* dpooled_ws,
+                            void* dhidden, int B, int S, int E, int V, float eps, float l2_lambda, float loss_scale,
+                            float l2_scale, void* stream) {
+  (void)eps;
+  VLB_REQUIRE(hidden && wmask && ln1_w && ln2_w && ridge_w && y && stats && pooled_raw && sumw && zhat && ln2_rstd && z &&
+                  pred && d_ridge_w && d_ridge_b && d_ln2_w && d_ln2_b && d_ln1_w && d_ln1_b && ws && dz_ws && dpooled_ws,
+              "head_bwd: null argument");
+  VLB_REQUIRE(B > 0 && S > 0 && V > 0 && E % 8 == 0 && E > 0 && E <= 8192, "head_bwd: bad shape");
+  hipStream_t st = as_stream(stream);
+  const float gscale = loss_scale * 2.f / ((float)B * (float)V);
+  const int rblk = (V + RIDGE_ROWS - 1) / RIDGE_ROWS;
+  hipLaunchKernelGGL(ridge_bwd_w_kernel, dim3(rblk), dim3(256), 0, st, (const bf16*)ridge_w, (const bf16*)z, pred, y,
+                     d_ridge_w, d_ridge_b, B, E, V, gscale, l2_scale * 2.f * l2_lambda);
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ridge_bwd_z_kernel, dim3((E + 511) / 512, DZ_SPLIT), dim3(256), 0, st, (const bf16*)ridge_w, pred,
+                     y, ws, B, E, V, gscale);
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, ws, (const bf16*)ln1_w, (const bf16*)ln2_w,
+                     keep_scale, pooled_raw, sumw, zhat, ln2_rstd, d_ln2_w, d_ln2_b, d_ln1_w, d_ln1_b, dz_ws,
+                     dpooled_ws, B, E);
+  VLB_LAUNCH_CHECK();
+  if (dhidden) {
+    const int64_t rows = (int64_t)B * S;
+    hipLaunchKernelGGL(head_dhidden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)hidden,
+                       wmask, stats, dpooled_ws, (bf16*)dhidden, S, E, rows);
+    VLB_LAUNCH_CHECK();
+  }
+  return VLB_OK;
+}

@@ -1,0 +1,245 @@
+"""Drop-in mirror of the reference's ``src.litmodule`` (VLBLitModule / VLBLitModuleConfig).
+
+Same class names, the same 16 config fields, the same hooks with the same meaning
+(src/litmodule/videollama2_vlb_litmodule.py:126-379): ``configure_model``, ``make_weight_mask``,
+``forward(x_video, x_lang, weight_mask, attention_mask)`` -> ``(regression_output, l2_reg)``,
+``training_step(batch)`` -> scalar loss (no batch_idx), ``validation_step(batch)`` ->
+``{'loss','brain_preds','brain_vals'}``, ``configure_optimizers()`` -> ``([opt],[{scheduler...}])``,
+``self.log("train/brain_loss", ...)``.  Module attribute names ``nnmodule``, ``hrf_layer``,
+``ridge_layer``, ``layer_norm1``, ``layer_norm2``, ``dropout`` are kept.
+
+What differs, on purpose: all arithmetic runs in libvlb HIP kernels; the backward pass is explicit
+(``training_step`` leaves fp32 gradients in ``param.grad`` of the trainable masters and returns the
+loss), because there is no autograd graph through hand-written kernels.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .backbone import Backbone, Weights
+from .geometry import Geometry, geometry_7b, geometry_mini
+from .head import HEAD_PARAMS, BrainHead
+from .optim import VlbAdamW
+
+try:  # real Lightning if present, else the minimal shim used by phantom_vlb_amd.trainer
+    from lightning.pytorch import LightningModule as _Base  # type: ignore
+    _HAVE_LIGHTNING = True
+except Exception:  # pragma: no cover - lightning is absent in the build image
+    _HAVE_LIGHTNING = False
+
+    class _Base:
+        def __init__(self):
+            self.training = True
+            self.logged: dict[str, float] = {}
+            self.trainer = None
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+        def train(self, mode: bool = True):
+            self.training = mode
+            return self
+
+        def eval(self):
+            return self.train(False)
+
+
+@dataclass
+class VLBLitModuleConfig:
+    """Field for field the reference's dataclass (src/litmodule/...:138-153) plus optional extras."""
+    model_path: str
+    freeze_backbone: bool
+    use_lora: bool
+    lora_r: int | None
+    lora_alpha: int | None
+    lora_dropout: float | None
+    dropout_rate: float
+    num_target: int
+    l2_lambda: float
+    lr: float
+    betas: list[float]
+    eps: float
+    weight_decay: float
+    lr_scheduler_name: str
+    last_epoch: int
+    t_max: int
+    # ---- extras (not in the reference; all optional)
+    geometry: str = "7b"            # "7b" | "mini"
+    init_seed: int = 1234
+    gradient_clip_val: float = 1.0  # the Trainer's gradient_clip_val, applied inside the fused AdamW
+
+    def __post_init__(self):
+        self.dtype = torch.bfloat16      # reference :155
+        self.device_map = "auto"         # reference :157 (degenerate on one device)
+
+
+def resolve_geometry(cfg: VLBLitModuleConfig) -> Geometry:
+    kw = dict(num_target=cfg.num_target, l2_lambda=cfg.l2_lambda)
+    if cfg.use_lora:
+        kw.update(lora_r=cfg.lora_r, lora_alpha=cfg.lora_alpha)
+    return geometry_mini(**kw) if cfg.geometry == "mini" else geometry_7b(**kw)
+
+
+class _Attr:
+    """Tiny namespace so ``self.nnmodule.config.hidden_size`` etc. read as in the reference."""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class VLBLitModule(_Base):
+    def __init__(self, config: VLBLitModuleConfig) -> None:
+        super().__init__()
+        self.config = config
+        self._device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        self._step = 0
+        self.world_size = 1
+        self.rank = 0
+
+    @property
+    def device(self):
+        return self._device
+
+    # ------------------------------------------------------------------ model
+    def configure_model(self, state_dict: dict | None = None, head_state: dict | None = None) -> None:
+        """reference :206-226.  The hub checkpoint is unreachable offline: weights are
+        random-initialised on the device unless a state dict (upstream naming) is handed in."""
+        if getattr(self, "nnmodule", None) is not None:
+            return
+        cfg = self.config
+        g = self.geometry = resolve_geometry(cfg)
+        dev = self.device
+        torch.cuda.set_device(dev)
+        if state_dict is None:
+            if cfg.model_path and os.path.isdir(cfg.model_path):
+                state_dict = load_safetensors_dir(cfg.model_path)
+            else:
+                warnings.warn(f"model_path={cfg.model_path!r} is not a local directory: random-initialising "
+                              f"the {cfg.geometry} architecture (no network / HF cache in this environment)")
+                state_dict = Weights.random_state_dict(g, dev, seed=cfg.init_seed)
+        weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora))
+        del state_dict
+        self.backbone = Backbone(g, weights)
+        self.nnmodule = _Attr(config=_Attr(hidden_size=g.dim, tokenizer_model_max_length=g.max_len,
+                                           num_frames=g.num_frames, use_cache=False), backbone=self.backbone)
+        self.head = BrainHead(g.dim, cfg.num_target, cfg.l2_lambda, g.ln_eps, dev, sd=head_state, seed=cfg.init_seed)
+        # reference attribute names
+        self.hrf_layer = self.head
+        self.ridge_layer = self.head
+        self.layer_norm1 = self.head
+        self.layer_norm2 = self.head
+        self.dropout = _Attr(p=cfg.dropout_rate)
+        self.lora = None
+        if cfg.use_lora:
+            from .lora import LoraState
+            self.lora = LoraState(g, weights, cfg.lora_r, cfg.lora_alpha, cfg.lora_dropout or 0.0, dev, seed=cfg.init_seed)
+
+    def trainable_named_parameters(self):
+        """(name, fp32 master tensor) of everything AdamW updates: head always; LoRA A/B when use_lora
+        (reference :86-120: backbone frozen / peft freezes the base)."""
+        out = [(n, self.head.master[n]) for n in HEAD_PARAMS]
+        if self.lora is not None:
+            out += self.lora.named_masters()
+        return out
+
+    def parameters(self):
+        return [p for _, p in self.trainable_named_parameters()]
+
+    # ------------------------------------------------------------------ pieces of the step
+    def make_weight_mask(self, pad_vals, vis_weights, lang_weights, lang_len, max_len):
+        """reference :178-203 - one launch; values rounded to bf16 like the reference's mask."""
+        g = self.geometry
+        feature_len = vis_weights.shape[1] * g.ds_grid * g.ds_grid + lang_len - 1
+        assert feature_len == max_len
+        dev = self.device
+        return ops.weight_mask(pad_vals.to(dev, torch.int64), vis_weights.to(dev, torch.float64),
+                               lang_weights.to(dev, torch.float64), g.ds_grid * g.ds_grid, max_len, round_bf16=True)
+
+    def _vision_tensor(self, x_video):
+        if isinstance(x_video, (list, tuple)):          # reference passes [(tensor, "video"), ...]
+            x_video = torch.stack([v[0] if isinstance(v, (list, tuple)) else v for v in x_video])
+        return x_video.to(self.device, torch.float32).contiguous()
+
+    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None):
+        """reference :229-256 -> (regression_output fp32 [B,V], l2_reg).  attention_mask is re-derived
+        on the device from the ids (ids != 0), exactly what the reference passes in (:271)."""
+        vis = self._vision_tensor(x_video)
+        ids = x_lang.to(self.device, torch.int64).contiguous()
+        B = ids.shape[0]
+        if self.lora is not None and self.training:
+            hidden, key_mask = self.lora.forward(self.backbone, vis, ids)
+        else:
+            hidden, key_mask = self.backbone.forward(vis, ids)
+        if y is None:
+            y = torch.zeros(B, self.config.num_target, dtype=torch.float32, device=self.device)
+        pred, terms = self.head.forward(hidden, weight_mask, y, keep_scale)
+        self._loss_terms = terms
+        return pred, terms[1]
+
+    def _common_step(self, batch, train: bool):
+        cfg, g = self.config, self.geometry
+        dev = self.device
+        x_lang = batch["language"].to(dev).long()
+        wm = self.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], x_lang.shape[1],
+                                   self.nnmodule.config.tokenizer_model_max_length)
+        y = batch["timeseries"].to(dev, torch.float32).to(torch.bfloat16).float().contiguous()   # reference :288
+        keep = None
+        if train and cfg.dropout_rate > 0:
+            keep = (torch.rand(x_lang.shape[0], g.dim, device=dev) >= cfg.dropout_rate).float() / (1.0 - cfg.dropout_rate)
+        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep)
+        return pred, y, self._loss_terms
+
+    def training_step(self, batch):
+        """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
+        self.train(True) if not _HAVE_LIGHTNING else None
+        pred, y, terms = self._common_step(batch, train=True)
+        need_dh = self.lora is not None
+        inv_world = 1.0 / self.world_size
+        dh = self.head.backward(need_dhidden=need_dh, loss_scale=inv_world, l2_scale=inv_world)
+        if need_dh:
+            self.lora.backward(self.backbone, dh)
+        for n, p in self.trainable_named_parameters():
+            p.grad = self.head.grads[n] if n in self.head.grads else self.lora.grads[n]
+        loss = terms[2]
+        self.log("train/brain_loss", loss)
+        return loss
+
+    def validation_step(self, batch):
+        """reference :309-342."""
+        was = self.training
+        self.train(False)
+        pred, y, terms = self._common_step(batch, train=False)
+        self.train(was)
+        loss = terms[2].clone()
+        self.log("val/brain_loss", loss)
+        return {"loss": loss, "brain_preds": pred.clone(), "brain_vals": y}
+
+    # ------------------------------------------------------------------ optimiser
+    def configure_optimizers(self):
+        """reference :345-379: AdamW over the trainables + CosineAnnealingLR stepped every step."""
+        cfg = self.config
+        named = self.trainable_named_parameters()
+        bf16_copies = {n: self.head.compute[n] for n in HEAD_PARAMS}
+        if self.lora is not None:
+            bf16_copies.update(self.lora.compute_copies())
+        self.optimizer = VlbAdamW(named, bf16_copies, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
+                                  weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val)
+        self.lr_scheduler_args = {"last_epoch": cfg.last_epoch, "T_max": cfg.t_max}
+        self.scheduler = getattr(torch.optim.lr_scheduler, cfg.lr_scheduler_name)(self.optimizer, **self.lr_scheduler_args)
+        return [self.optimizer], [{"scheduler": self.scheduler, "interval": "step", "frequency": 1}]
+
+
+def load_safetensors_dir(path: str) -> dict:
+    """Load every *.safetensors shard of a local checkpoint directory (upstream naming)."""
+    from safetensors.torch import load_file
+    sd = {}
+    for f in sorted(os.listdir(path)):
+        if f.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(path, f)))
+    if not sd:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    return sd

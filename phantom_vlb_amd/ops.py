@@ -1,0 +1,197 @@
+"""Tensor-level wrappers over the libvlb C-ABI (torch is plumbing: device memory + streams).
+
+Every function takes CUDA(=HIP) tensors, passes raw pointers and the current stream to the
+HIP kernels and returns torch tensors.  There is no CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib
+
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("phantom_vlb_amd ops need GPU tensors (no CPU fallback)")
+    return t
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=None):
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + a2 @ w2^T + bias) + residual   (all bf16, fp32 accumulate)."""
+    _dev(a)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    K2 = 0
+    if a2 is not None:
+        K2 = a2.shape[1]
+        assert w2.shape == (N, K2) and a2.shape[0] == M
+    check(lib.vlb_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                            M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
+                            _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
+                            w2.stride(0) if w2 is not None else 0, K2, _stream()), "vlb_gemm_bf16")
+    return out
+
+
+def transpose(x):
+    R, C = x.shape
+    out = torch.empty(C, R, dtype=BF16, device=x.device)
+    check(lib.vlb_transpose_bf16(_dev(x).data_ptr(), out.data_ptr(), R, C, _stream()), "vlb_transpose_bf16")
+    return out
+
+
+def attention_fwd(q, k, v, B, S, Hq, Hkv, D, causal, scale, key_mask=None, need_lse=False, out=None):
+    """q/k/v: 2-D views [B*S, H*D] (row stride = token stride, may be slices of a packed qkv buffer)."""
+    _dev(q)
+    if out is None:
+        out = torch.empty(B * S, Hq * D, dtype=BF16, device=q.device)
+    lse = torch.empty(B, Hq, S, dtype=torch.float32, device=q.device) if need_lse else None
+    check(lib.vlb_attention_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                out.data_ptr(), out.stride(0), _p(lse), _p(key_mask), B, S, Hq, Hkv, D,
+                                1 if causal else 0, float(scale), _stream()), "vlb_attention_fwd")
+    return (out, lse) if need_lse else out
+
+
+def rmsnorm(x, w, eps, out=None):
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vlb_rmsnorm_fwd(_dev(x).data_ptr(), w.data_ptr(), out.data_ptr(), rows, dim, eps, _stream()), "vlb_rmsnorm_fwd")
+    return out
+
+
+def rmsnorm_bwd(x, w, dy, eps, dx_in=None, out=None):
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vlb_rmsnorm_bwd(_dev(x).data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx_in), out.data_ptr(), rows, dim, eps,
+                              _stream()), "vlb_rmsnorm_bwd")
+    return out
+
+
+def layernorm(x, w, b, eps, residual=None, act=ACT_NONE, out=None):
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vlb_layernorm_fwd(_dev(x).data_ptr(), w.data_ptr(), b.data_ptr(), _p(residual), out.data_ptr(), rows, dim,
+                                eps, act, _stream()), "vlb_layernorm_fwd")
+    return out
+
+
+def rope_(x, cos, sin, B, S, heads, D, sign=1):
+    """In place on the first heads*D columns of the 2-D view x [B*S, >=heads*D]."""
+    check(lib.vlb_rope_inplace(_dev(x).data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(), B, S, heads, D, sign,
+                               _stream()), "vlb_rope_inplace")
+    return x
+
+
+def swiglu(gu, out=None):
+    rows, ff2 = gu.shape
+    if out is None:
+        out = torch.empty(rows, ff2 // 2, dtype=BF16, device=gu.device)
+    check(lib.vlb_swiglu_fwd(_dev(gu).data_ptr(), out.data_ptr(), rows, ff2 // 2, _stream()), "vlb_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu, dout, out=None):
+    rows, ff2 = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    check(lib.vlb_swiglu_bwd(_dev(gu).data_ptr(), dout.data_ptr(), out.data_ptr(), rows, ff2 // 2, _stream()), "vlb_swiglu_bwd")
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.vlb_add_bf16(_dev(a).data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "vlb_add_bf16")
+    return out
+
+
+def patchify(vision_f32, P, Kpad):
+    N, C, H, W = vision_f32.shape
+    assert C == 3 and vision_f32.dtype == torch.float32 and vision_f32.is_contiguous()
+    out = torch.empty(N * (H // P) * (W // P), Kpad, dtype=BF16, device=vision_f32.device)
+    check(lib.vlb_patchify(_dev(vision_f32).data_ptr(), out.data_ptr(), N, H, W, P, Kpad, _stream()), "vlb_patchify")
+    return out
+
+
+def vit_assemble(patch_emb, cls, pos, N, G, D):
+    out = torch.empty(N * (G + 1), D, dtype=BF16, device=patch_emb.device)
+    check(lib.vlb_vit_assemble(_dev(patch_emb).data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), N, G, D,
+                               _stream()), "vlb_vit_assemble")
+    return out
+
+
+def drop_cls(tokens, N, G, D):
+    out = torch.empty(N * G, D, dtype=BF16, device=tokens.device)
+    check(lib.vlb_drop_cls(_dev(tokens).data_ptr(), out.data_ptr(), N, G, D, _stream()), "vlb_drop_cls")
+    return out
+
+
+def dwconv3x3(x, w9, N, H, W, C):
+    out = torch.empty_like(x)
+    check(lib.vlb_dwconv3x3(_dev(x).data_ptr(), w9.data_ptr(), out.data_ptr(), N, H, W, C, _stream()), "vlb_dwconv3x3")
+    return out
+
+
+def se_pool(x, N, HW, C):
+    out = torch.empty(N, C, dtype=BF16, device=x.device)
+    check(lib.vlb_se_pool(_dev(x).data_ptr(), out.data_ptr(), N, HW, C, _stream()), "vlb_se_pool")
+    return out
+
+
+def se_scale(x, gate, N, HW, C, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.vlb_se_scale(_dev(x).data_ptr(), gate.data_ptr(), out.data_ptr(), N, HW, C, _stream()), "vlb_se_scale")
+    return out
+
+
+def im2col3d(x, B, T, H, W, C):
+    T2, H2, W2 = T // 2 + 1, H // 2 + 1, W // 2 + 1
+    out = torch.empty(B * T2 * H2 * W2, 8 * C, dtype=BF16, device=x.device)
+    check(lib.vlb_im2col3d_k2s2p1(_dev(x).data_ptr(), out.data_ptr(), B, T, H, W, C, _stream()), "vlb_im2col3d_k2s2p1")
+    return out
+
+
+def splice_embed(ids, embed_w, video_tokens, Nv, video_id, err_flag):
+    B, L = ids.shape
+    D = embed_w.shape[1]
+    S = L - 1 + Nv
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    out = torch.empty(B * S, D, dtype=BF16, device=ids.device)
+    mask = torch.empty(B, S, dtype=torch.uint8, device=ids.device)
+    check(lib.vlb_splice_embed(_dev(ids).data_ptr(), embed_w.data_ptr(), video_tokens.data_ptr(), out.data_ptr(),
+                               mask.data_ptr(), err_flag.data_ptr(), B, L, Nv, D, video_id, embed_w.shape[0],
+                               _stream()), "vlb_splice_embed")
+    return out, mask
+
+
+def weight_mask(padvals, vis_w, lang_w, tokens_per_frame, S, round_bf16=True):
+    B, F = vis_w.shape
+    assert padvals.dtype == torch.int64 and vis_w.dtype == torch.float64 and lang_w.dtype == torch.float64
+    out = torch.empty(B, S, dtype=torch.float32, device=padvals.device)
+    check(lib.vlb_weight_mask(_dev(padvals).contiguous().data_ptr(), vis_w.contiguous().data_ptr(),
+                              lang_w.contiguous().data_ptr(), out.data_ptr(), B, F, lang_w.shape[1], tokens_per_frame, S,
+                              1 if round_bf16 else 0, _stream()), "vlb_weight_mask")
+    return out
+
+
+def cast_bf16(x_f32):
+    out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    check(lib.vlb_cast_f32_to_bf16(_dev(x_f32).data_ptr(), out.data_ptr(), x_f32.numel(), _stream()), "vlb_cast_f32_to_bf16")
+    return out
