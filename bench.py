@@ -1,0 +1,167 @@
+"""Headline benchmark: clips/sec of one fine-tuning step (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3          # configs[1]: 7B frozen backbone + 2k head, B=5/GPU
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = forward through CLIP tower + STC connector + splice + 32 Mistral layers + brain head,
+head backward, global-norm clip, AdamW, cosine LR - all on libvlb HIP kernels, inputs resident in
+HBM.  One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the 256x256 MFMA GEMM on the gate/up projection, timed with HIP events on its own stream inside the
+timed region) and `cpu_baseline` (the oracle on the host cores, bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
+# algorithmic TFLOP per clip
+TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="frozen", choices=["frozen", "lora"])
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
+    ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(g7, num_target):
+    """Oracle (oracle/vlb_oracle.py, kind 'port') on the host cores: ONE clip through 2 ViT layers,
+    the full connector, 2 decoder layers and the full head in fp32; ViT/decoder times are scaled to
+    23/32 layers.  Returns (clips_per_s, cores, sample description)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vlb_oracle as O
+    import dataclasses
+    cores = torch.get_num_threads()
+    g = dataclasses.replace(O.geometry_7b(num_target=num_target), vit_layers=3, layers=2)
+    p = O.init_params(g, seed=1)
+    batch = O.synthetic_batch(g, 1, seed=1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        pix = batch["vision"].reshape(g.num_frames, 3, g.image_size, g.image_size)
+        vit = O.clip_tower(p, pix, g).view(1, g.num_frames, -1, g.vit_dim)
+        t1 = time.perf_counter()
+        vid = O.stc_connector(p, vit, g)
+        t2 = time.perf_counter()
+        emb, km = O.splice_multimodal(p["model.embed_tokens.weight"], batch["language"].long(), vid)
+        hid = O.mistral_decoder(p, emb, km, g)
+        t3 = time.perf_counter()
+        wm = O.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], g.lang_len, g.max_len, g.ds_grid ** 2)
+        pred, l2, _ = O.brain_head(p, hid, wm, g)
+        t4 = time.perf_counter()
+    t_vit, t_conn, t_dec, t_head = t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    total = t_vit * (23 / 2) + t_conn + t_dec * (32 / 2) + t_head
+    sample = (f"1 clip fp32 forward: 2 ViT layers {t_vit:.1f}s x23/2 + connector {t_conn:.1f}s + 2 decoder layers "
+              f"{t_dec:.1f}s x32/2 + head {t_head:.2f}s = {total:.0f}s/clip (extrapolated, forward only)")
+    return 1.0 / total, cores, sample
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.synthetic import synthetic_batch
+
+    lora = a.workload == "lora"
+    B = a.batch or (3 if lora else 5)
+    cfg = VLBLitModuleConfig(
+        model_path="DAMO-NLP-SG/VideoLLaMA2-7B", freeze_backbone=not lora, use_lora=lora,
+        lora_r=16 if lora else None, lora_alpha=32 if lora else None, lora_dropout=0.1 if lora else None,
+        dropout_rate=0.1, num_target=2048 if a.geometry == "7b" else 128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999],
+        eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000,
+        geometry=a.geometry)
+    import warnings
+    warnings.simplefilter("ignore")
+    m = VLBLitModule(cfg)
+    m.world_size, m.rank = world, rank
+    m.configure_model()
+    opt, sch = m.configure_optimizers()
+    opt, sch = opt[0], sch[0]["scheduler"]
+    if world > 1:
+        from phantom_vlb_amd.parallel import attach_data_parallel
+        attach_data_parallel(m, opt)
+    g = m.geometry
+    batch = synthetic_batch(g, B, seed=1234 + rank, device=dev)
+
+    def step():
+        loss = m.training_step(batch)
+        opt.step()
+        sch.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    # ---- dominant-kernel timing: event pairs around every gate/up GEMM launch of the timed steps
+    probe = ops.enable_gemm_probe(N=2 * g.ff, K=g.dim)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.disable_gemm_probe()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms, launches, (pM, pN, pK) = probe.result()
+    if rank == 0:
+        clips = world * B * a.steps
+        value = clips / dt
+        flops_launch = 2.0 * pM * pN * pK
+        achieved = flops_launch / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0
+        out = {
+            "metric": "clips/sec fine-tune VideoLLaMA2-7B+LoRA->2k-voxel head, 1/2/4/8 MI355X",
+            "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16"
+                                    if not lora else "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16")
+                       if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
+                       "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
+                       "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}",
+                       "loss": round(float(loss), 6),
+                       "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload], 1),
+                       "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] / PEAK_BF16_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<256,256> on gate/up projection "
+                         f"[{pM}x{pK}]x[{pN}x{pK}]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
+        }
+        if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":
+            v, cores, sample = cpu_baseline(g, cfg.num_target)
+            out["cpu_baseline"] = {"value": round(v, 6), "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,7 +158,7 @@ def main():
 
     # ---- mini config end-to-end golden (configs[0]): frozen backbone and LoRA variants
     for tag, lora in (("frozen", False), ("lora", True)):
-        p = O.init_params(g, seed=1234, lora=lora, lora_b_std=0.02 if lora else 0.0)
+        p = O.round_bf16(O.init_params(g, seed=1234, lora=lora, lora_b_std=0.02 if lora else 0.0))
         batch = O.synthetic_batch(g, batch=4, seed=1234)
         names = O.trainable_names(p, freeze_backbone=not lora, use_lora=lora)
         for n in names:

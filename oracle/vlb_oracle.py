@@ -490,10 +490,17 @@ def brain_head(p, hidden, weight_mask, g: Geometry, keep_mask=None, dropout_p=0.
     return pred, l2, dict(ln1=h, pooled=pooled, ln2=z)
 
 
+def round_bf16(p: dict) -> dict:
+    """The reference holds every parameter in bf16 (torch_dtype=bf16, head dtype=bf16;
+    src/litmodule/...:155,211-225): the oracle keeps fp32 MATH on those bf16-valued weights."""
+    return {k: v.detach().to(torch.bfloat16).float() for k, v in p.items()}
+
+
 def backbone_forward(p, batch, g: Geometry, stages=None, lora_drop=None):
-    """vision/language of a batch -> post-norm hidden (B,max_len,dim) and key mask."""
+    """vision/language of a batch -> post-norm hidden (B,max_len,dim) and key mask.
+    Pixels are rounded to bf16 first, as training_step does (src/litmodule/...:267)."""
     B = batch["vision"].shape[0]
-    pix = batch["vision"].float().reshape(B * g.num_frames, 3, g.image_size, g.image_size)
+    pix = batch["vision"].to(torch.bfloat16).float().reshape(B * g.num_frames, 3, g.image_size, g.image_size)
     vit = clip_tower(p, pix, g).view(B, g.num_frames, g.grid * g.grid, g.vit_dim)
     vid = stc_connector(p, vit, g)
     ids = batch["language"].long()
@@ -510,8 +517,10 @@ def training_loss(p, batch, g: Geometry, keep_mask=None, dropout_p=0.0, stages=N
     hidden, _ = backbone_forward(p, batch, g, stages, lora_drop)
     wm = make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"],
                           batch["language"].shape[1], g.max_len, g.ds_grid * g.ds_grid)
+    wm = wm.to(torch.bfloat16).float()                       # the reference builds the mask in bf16 (:190-194)
+    y = batch["timeseries"].to(torch.bfloat16).float()       # :288
     pred, l2, hs = brain_head(p, hidden, wm, g, keep_mask, dropout_p)
-    loss = F.mse_loss(pred, batch["timeseries"].float()) + l2
+    loss = F.mse_loss(pred, y) + l2
     if stages is not None:
         stages.update(weight_mask=wm, pred=pred, l2=l2, loss=loss, **{f"head_{k}": v for k, v in hs.items()})
     return loss, pred

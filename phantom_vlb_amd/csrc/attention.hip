@@ -258,3 +258,309 @@ extern "C" int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk,
   if (D == 128) return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
   return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
 }
+
+// =================================================================================================
+// Backward (D = 128 only: the decoder; the frozen ViT never needs one).
+//
+// A workgroup = 4 waves owns 128 keys of one (batch, kv-head) and sweeps the q-heads of its GQA
+// group x 32-row query blocks, so dK/dV accumulate in registers with no cross-workgroup sum.
+// Scores are computed with the KEY ON THE LANE (S = Q.K^T, dP = dO.V^T): their accumulators are then
+// directly the B operands of dV^T += dO^T.P and dK^T += Q^T.dS (transposed A fragments come from the
+// row-major Q/dO LDS images via ds_read_b64_tr_b16).  Only dS crosses LDS (image [key][q]) so that
+// each wave can form one 32-column slice of dQ over all 128 keys; dQ is summed across key blocks
+// with fp32 atomics (two 128-byte segments per wave-instruction), then converted to bf16.
+// =================================================================================================
+namespace {
+
+constexpr int BK_KEYS = 128;   // keys per workgroup
+constexpr int BQ = 32;         // queries per inner block
+
+struct AttnBwdArgs {
+  const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
+  const float* lse; const float* delta; const uint8_t* mask;
+  bf16* dk; bf16* dv; float* dq_acc;
+  int ldq, ldk, ldv, lddo, lddk, lddv;
+  int B, S, Hq, Hkv;
+  float scale;
+};
+
+__device__ __forceinline__ int sw2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+// delta[b,h,s] = sum_d dout*out ; one 16-lane group per (token, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, int ldo, const bf16* __restrict__ d_o,
+                                                         int lddo, float* __restrict__ delta, int S, int Hq, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (token, head) index
+  const int c = threadIdx.x & 15;
+  float s = 0.f;
+  if (gid < total) {
+    const int h = gid % Hq; const int64_t tok = gid / Hq;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + tok * ldo + h * 128 + c * 8);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(d_o + tok * lddo + h * 128 + c * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)b[i];
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (gid < total && c == 0) {
+    const int h = gid % Hq; const int64_t tok = gid / Hq;
+    const int64_t b = tok / S; const int sidx = tok % S;
+    delta[(b * Hq + h) * S + sidx] = s;
+  }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
+  constexpr int D = 128, ROWB = 256;
+  constexpr int K_OFF = 0, V_OFF = BK_KEYS * ROWB;                 // 32 KB each
+  constexpr int QT_OFF = 2 * BK_KEYS * ROWB;                       // [2][Q tile 8 KB | dO tile 8 KB]
+  constexpr int QT_BYTES = BQ * ROWB;
+  constexpr int T_OFF = QT_OFF + 4 * QT_BYTES;                     // dS^T image [128 keys][32 q] bf16 = 8 KB
+  constexpr int L_OFF = T_OFF + BK_KEYS * 64;                      // [2][lse 32 f32 | delta 32 f32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const int k0 = kb * BK_KEYS;
+  const int grp = p.Hq / p.Hkv;
+  const int ql = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int sr = lane >> 4, sp = lane & 15;    // staging: row within a 4-row piece, slot
+
+  const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
+  const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
+  // ---- stage K and V once (8 pieces of 4 rows per wave each)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int piece = 4 * i + wave, r = piece * 4 + sr;
+    const int key = min(k0 + r, p.S - 1);
+    glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, smem + K_OFF + piece * 1024);
+    glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
+  }
+  const int nqb = (p.S + BQ - 1) / BQ;
+  const int qb0 = CAUSAL ? (k0 / BQ) : 0;
+  const int nq = nqb - qb0;                 // query blocks per head
+  const int total = nq * grp;               // (head, q-block) items of this workgroup
+
+  auto stage_q = [&](int buf, int item) {
+    const int hq = hkv * grp + item / nq, qb = qb0 + item % nq;
+    const bf16* qbase = p.q + (int64_t)b * p.S * p.ldq + hq * D;
+    const bf16* dobase = p.dout + (int64_t)b * p.S * p.lddo + hq * D;
+    char* qt = smem + QT_OFF + buf * 2 * QT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 4 * i + wave, r = piece * 4 + sr;
+      const int qr = min(qb * BQ + r, p.S - 1);
+      glds16(qbase + (int64_t)qr * p.ldq + (sp ^ sw2(r)) * 8, qt + piece * 1024);
+      glds16(dobase + (int64_t)qr * p.lddo + (sp ^ sw2(r)) * 8, qt + QT_BYTES + piece * 1024);
+    }
+    if (tid < 64) {
+      const int qr = min(qb * BQ + (tid & 31), p.S - 1);
+      const float* src = (tid < 32 ? p.lse : p.delta) + ((int64_t)b * p.Hq + hq) * p.S + qr;
+      reinterpret_cast<float*>(smem + L_OFF)[buf * 64 + tid] = *src;
+    }
+  };
+
+  f32x16 dkt[4], dvt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
+
+  if (total > 0) stage_q(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // lane-constant LDS offsets
+  const int krow = wave * 32 + ql;                       // this lane's key row inside the K/V tiles
+  int kv_rd[8];                                          // row reads of K/V: chunk 2ks+h
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kv_rd[ks] = krow * ROWB + (((2 * ks + h) ^ sw2(krow)) << 4);
+  int q_rd[8];                                           // row reads of Q/dO tiles (row ql)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) q_rd[ks] = ql * ROWB + (((2 * ks + h) ^ sw2(ql)) << 4);
+  // transposed reads of the Q/dO tiles: rows 16s + 8e + 4h + tq, chunk 4dt + 2g1 + (tp>>1)
+  int qt_rd[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 8 * e + 4 * h + tq;
+      qt_rd[dt][e] = r * ROWB + (((4 * dt + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
+    }
+  // transposed reads of K for dQ (B operand): rows 16s + 8h + 4e + tq, chunk 4*wave + 2g1 + (tp>>1)
+  int kt_rd[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int r = 8 * h + 4 * e + tq;
+    kt_rd[e] = r * ROWB + (((4 * wave + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
+  }
+  // transposed reads of T (dS^T image, 64-byte rows): rows 16s + 8h + 4e + tq, cols 16g1 + 4tp
+  int t_rd[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) t_rd[e] = (8 * h + 4 * e + tq) * 64 + (16 * g1 + 4 * tp) * 2;
+
+  const float c2 = p.scale * 1.44269504088896341f;
+  const int key = k0 + krow;
+  bool key_ok = key < p.S;
+  if (key_ok && p.mask) key_ok = p.mask[(int64_t)b * p.S + key] != 0;
+
+  for (int item = 0; item < total; ++item) {
+    const int cur = item & 1;
+    if (item + 1 < total) stage_q(cur ^ 1, item + 1);
+    const int hq = hkv * grp + item / nq, qb = qb0 + item % nq;
+    const char* qt = smem + QT_OFF + cur * 2 * QT_BYTES;
+    const char* dot = qt + QT_BYTES;
+    const float* ls = reinterpret_cast<const float*>(smem + L_OFF) + cur * 64;
+    const int q0 = qb * BQ;
+
+    // ---- S = Q.K^T and dP = dO.V^T  (key on lane)
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + q_rd[ks]);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + K_OFF + kv_rd[ks]);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);
+      const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_rd[ks]);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + kv_rd[ks]);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
+    }
+    // ---- P = exp(S*scale - lse), dS = scale * P * (dP - delta); rows q = (r&3) + 8(r>>2) + 4h
+    bf16x8 pb[2], dsb[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * h);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int qrow = q0 + 8 * g + 4 * h + e;
+        bool ok = key_ok && qrow < p.S;
+        if (CAUSAL) ok = ok && (key <= qrow);
+        const float pv = ok ? exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
+        const float ds = pv * (pacc[r] - d4[e]) * p.scale;
+        pb[r >> 3][r & 7] = (bf16)pv;
+        dsb[r >> 3][r & 7] = (bf16)ds;
+      }
+    }
+    // ---- dS^T image: row = key (krow), cols q = 8g + 4h + {0..3}  (8-byte stores)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
+      *reinterpret_cast<bf16x4*>(smem + T_OFF + krow * 64 + (8 * g + 4 * h) * 2) = t;
+    }
+    // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dot + qt_rd[dt][0] + 16 * s * ROWB));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dot + qt_rd[dt][1] + 16 * s * ROWB));
+        const bf16x8 dot_f = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_f, pb[s], dvt[dt], 0, 0, 0);
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qt + qt_rd[dt][0] + 16 * s * ROWB));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qt + qt_rd[dt][1] + 16 * s * ROWB));
+        const bf16x8 qt_f = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_f, dsb[s], dkt[dt], 0, 0, 0);
+      }
+    __syncthreads();   // dS^T image complete
+    // ---- dQ[:, 32*wave .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + T_OFF + t_rd[0] + 16 * s * 64));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + T_OFF + t_rd[1] + 16 * s * 64));
+      const bf16x8 dsf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+      const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + K_OFF + kt_rd[0] + 16 * s * ROWB));
+      const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + K_OFF + kt_rd[1] + 16 * s * ROWB));
+      const bf16x8 ktf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+      dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, ktf, dq, 0, 0, 0);
+    }
+    {
+      float* dqp = p.dq_acc + (((int64_t)b * p.S + q0) * p.Hq + hq) * D + 32 * wave + ql;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (q0 + qi < p.S) atomicAdd(dqp + (int64_t)qi * p.Hq * D, dq[r]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // next Q/dO tile landed; T and the current tile are free again
+  }
+
+  // ---- epilogue: dK^T/dV^T [d][key]: lane owns key, 4 consecutive d per register group
+  if (key < p.S) {
+    bf16* dkp = p.dk + ((int64_t)b * p.S + key) * p.lddk + hkv * D;
+    bf16* dvp = p.dv + ((int64_t)b * p.S + key) * p.lddv + hkv * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (bf16)dkt[dt][4 * g + e]; c[e] = (bf16)dvt[dt][4 * g + e]; }
+        *reinterpret_cast<bf16x4*>(dkp + 32 * dt + 8 * g + 4 * h) = a;
+        *reinterpret_cast<bf16x4*>(dvp + 32 * dt + 8 * g + 4 * h) = c;
+      }
+  }
+}
+
+// dq (bf16, strided) = dq_acc (fp32 [B*S, Hq*128])
+__global__ void dq_convert_kernel(const float* __restrict__ acc, bf16* __restrict__ dq, int lddq, int width, int64_t total) {
+  const int cpr = width >> 3;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / cpr; const int c = (idx % cpr) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(acc + row * width + c);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(acc + row * width + c + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = (bf16)a[i]; o[4 + i] = (bf16)b2[i]; }
+    *reinterpret_cast<bf16x8*>(dq + row * lddq + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
+                                 int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,
+                                 int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B,
+                                 int S, int Hq, int Hkv, int D, int causal, float scale, void* stream) {
+  VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta && dq_acc, "attention_bwd: null operand");
+  VLB_REQUIRE(D == 128, "attention_bwd: head dim %d unsupported (only 128: the decoder)", D);
+  VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
+  VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&
+                  lddk % 4 == 0 && lddv % 4 == 0, "attention_bwd: strides must keep vector alignment");
+  hipStream_t st = as_stream(stream);
+  const int64_t th = (int64_t)B * S * Hq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((th + 15) / 16)), dim3(256), 0, st, (const bf16*)out, ldo,
+                     (const bf16*)dout, lddo, delta, S, Hq, th);
+  VLB_LAUNCH_CHECK();
+  hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
+  if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+  AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask,
+                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
+  constexpr int LDS = 2 * BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed"); return VLB_ERR_LAUNCH; }
+    configured = true;
+  }
+  dim3 grid((S + BK_KEYS - 1) / BK_KEYS, Hkv, B);
+  if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), LDS, st, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), LDS, st, a);
+  VLB_LAUNCH_CHECK();
+  const int64_t total = (int64_t)B * S * (Hq * D / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dq_convert_kernel, dim3(blocks), dim3(256), 0, st, dq_acc, (bf16*)dq, lddq, Hq * D, total);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}

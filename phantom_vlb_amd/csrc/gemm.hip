@@ -192,6 +192,181 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the tile kernel.  The 8 waves form two groups of 4 (one wave of each group per
+// SIMD).  Every K-tile is two phases (k-steps of 32); a phase is a LOAD segment (12 ds_read_b128 of
+// fragments, plus the LDS-DMA issue of the tile after next) and a COMPUTE segment (32 MFMAs), separated
+// by workgroup barriers.  Group 1 runs one barrier interval behind group 0, so on every SIMD one wave
+// is always in its MFMA segment while its partner reads LDS: the matrix pipe never waits for loads.
+//   interval:      0    1    2    3    4   ...
+//   group 0:       L0   C0   L1   C1   L2  ...
+//   group 1:       -    L0   C0   L1   C1  ...
+// LDS-DMA for tile t+1 is issued in the first LOAD segment of tile t (its buffer was last read two
+// intervals earlier, and every LOAD segment ends with lgkmcnt(0) before its barrier), and is waited for
+// with ONE vmcnt(0) per tile placed just before the barrier that precedes the first read of tile t+1,
+// i.e. after ~3-4 intervals of flight.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
+  static_assert(WM * WN == 8 && WM % 2 == 0, "8 waves, groups split along M");
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 16, NT = TN / 16;
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LD = BM / 64, B_LD = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  int pid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
+    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  constexpr int GROUP_M = 4;
+  const int band = GROUP_M * p.tiles_n;
+  const int g0 = (pid / band) * GROUP_M;
+  const int gsz = min(p.tiles_m - g0, GROUP_M);
+  const int tm = g0 + (pid % band) % gsz;
+  const int tn = (pid % band) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int grp = wave >> 2;                       // 0: leads, 1: trails by one barrier interval
+
+  const int srow = (lane >> 3), sslot = lane & 7;
+  const bf16* a_src[A_LD]; const bf16* b_src[B_LD];
+  const bf16* a2_src[A_LD]; const bf16* b2_src[B_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int r = i * 64 + wave * 8 + srow;
+    const int c = sslot ^ ((r >> 1) & 7);
+    const int gm = min(m0 + r, p.M - 1);
+    a_src[i] = p.A + (int64_t)gm * p.lda + c * 8;
+    a2_src[i] = p.A2 ? p.A2 + (int64_t)gm * p.lda2 + c * 8 : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int r = i * 64 + wave * 8 + srow;
+    const int c = sslot ^ ((r >> 1) & 7);
+    b_src[i] = p.W + (int64_t)(n0 + r) * p.ldw + c * 8;
+    b2_src[i] = p.W2 ? p.W2 + (int64_t)(n0 + r) * p.ldw2 + c * 8 : nullptr;
+  }
+  const int nk1 = p.K / BK;
+  const int nk = nk1 + p.K2 / BK;
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE + wave * 8 * ROW_BYTES;
+    if (kt < nk1) {
+      const int ko = kt * BK;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) glds16(a_src[i] + ko, base + i * 64 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) glds16(b_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
+    } else {
+      const int ko = (kt - nk1) * BK;
+#pragma unroll
+      for (int i = 0; i < A_LD; ++i) glds16(a2_src[i] + ko, base + i * 64 * ROW_BYTES);
+#pragma unroll
+      for (int i = 0; i < B_LD; ++i) glds16(b2_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[MT][2], b_off[NT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = lds_off(wm * TM + i * 16 + fr, ks * 4 + fq);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = A_BYTES + lds_off(wn * TN + j * 16 + fr, ks * 4 + fq);
+
+#define PP_BARRIER()                                  \
+  do {                                                \
+    __builtin_amdgcn_sched_barrier(0);                \
+    __builtin_amdgcn_s_barrier();                     \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+#define PP_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
+#define PP_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  PP_VM0();
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();
+
+  bf16x8 af[MT], wf[NT];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // ---------------- LOAD segment
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i][ks]);
+      if (ks == 0 && kt >= 1 && kt + 1 < nk) stage((kt & 1) ^ 1, kt + 1);
+      PP_LGKM0();
+      if (ks == 1 && grp == 1 && kt >= 1) PP_VM0();
+      PP_BARRIER();
+      // ---------------- COMPUTE segment
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (ks == 1 && grp == 0 && kt >= 1) PP_VM0();
+      PP_BARRIER();
+    }
+  }
+  if (grp == 0) PP_BARRIER();
+#undef PP_BARRIER
+#undef PP_LGKM0
+#undef PP_VM0
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * TM + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + fq * 4;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+      }
+      if (p.act != VLB_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      if (p.residual) {
+        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic bounds-checked kernel: 64x64 tile, 256 threads (2x2 waves, each 32x32 = 2x2 MFMA tiles),
 // BK = 32, register staging into padded LDS rows.  Correct for every shape with K % 8 == 0.
 // ------------------------------------------------------------------------------------------------
@@ -261,6 +436,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   }
 }
 
+int g_variant = 1;      // 0: lock-step double buffer, 1: ping-pong wave groups (default)
+int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
+
 template <int BM, int BN, int WM, int WN>
 int launch_tile(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
@@ -276,6 +454,21 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = a.N / BN;
+  if (g_variant == 1) {
+    static bool configured_pp = false;
+    if (!configured_pp) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) {
+        vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+        return VLB_ERR_LAUNCH;
+      }
+      configured_pp = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
+    VLB_LAUNCH_CHECK();
+    return VLB_OK;
+  }
   hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
@@ -304,13 +497,9 @@ extern "C" int vlb_gemm_kernel_choice(int M, int N, int K, int K2) {
   const int cus = 256;
   if (N % 256 == 0) {
     const int t256 = ((M + 255) / 256) * (N / 256);
-    // prefer the bigger tile unless it leaves the last wave of tiles mostly empty
-    if (N % 128 == 0) {
-      const int t128 = ((M + 255) / 256) * (N / 128);
-      const float e256 = (float)t256 / (float)(((t256 + cus - 1) / cus) * cus);
-      const float e128 = (float)t128 / (float)(((t128 + cus - 1) / cus) * cus);
-      if (e128 > e256 + 0.08f) return 2;
-    }
+    // the 256x256 tile has the better MFMA:LDS ratio; fall back to 256x128 only when the grid
+    // would leave more than half of the chip idle
+    if (t256 < cus / 2) return 2;
     return 1;
   }
   if (N % 128 == 0) return 2;
@@ -342,7 +531,9 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
                       (((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2) % 16 == 0);
-  const int choice = vec_ok ? vlb_gemm_kernel_choice(M, N, K, K2) : 0;
+  int choice = vec_ok ? vlb_gemm_kernel_choice(M, N, K, K2) : 0;
+  if (choice != 0 && g_force_tile == 1 && N % 256 == 0) choice = 1;
+  if (choice != 0 && g_force_tile == 2 && N % 128 == 0) choice = 2;
   if (choice == 1) return launch_tile<256, 256, 2, 4>(a, s);
   if (choice == 2) return launch_tile<256, 128, 4, 2>(a, s);
   dim3 grid((N + 63) / 64, (M + 63) / 64);
@@ -350,6 +541,9 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
+
+// tuning hooks (not part of the stable ABI): kernel variant / forced tile
+extern "C" void vlb_gemm_set_variant(int variant, int force_tile) { g_variant = variant; g_force_tile = force_tile; }
 
 extern "C" int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {
   VLB_REQUIRE(in && out && R > 0 && C > 0, "transpose: bad args");

@@ -27,6 +27,35 @@ def _dev(t):
     return t
 
 
+class _GemmProbe:
+    """HIP-event pairs (on the launch stream) around every vlb_gemm_bf16 call of one (N,K) shape."""
+
+    def __init__(self, N, K):
+        self.N, self.K, self.M = N, K, 0
+        self.pairs = []
+
+    def result(self):
+        torch.cuda.synchronize()
+        if not self.pairs:
+            return 0.0, 0, (0, self.N, self.K)
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        return sum(ms) / len(ms), len(ms), (self.M, self.N, self.K)
+
+
+_probe = None
+
+
+def enable_gemm_probe(N, K):
+    global _probe
+    _probe = _GemmProbe(N, K)
+    return _probe
+
+
+def disable_gemm_probe():
+    global _probe
+    _probe = None
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + a2 @ w2^T + bias) + residual   (all bf16, fp32 accumulate)."""
     _dev(a)
@@ -39,10 +68,18 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     if a2 is not None:
         K2 = a2.shape[1]
         assert w2.shape == (N, K2) and a2.shape[0] == M
+    timed = _probe is not None and N == _probe.N and K == _probe.K
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _probe.M = M
+        _probe.pairs.append((e0, e1))
+        e0.record()
     check(lib.vlb_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
                             M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
                             _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
                             w2.stride(0) if w2 is not None else 0, K2, _stream()), "vlb_gemm_bf16")
+    if timed:
+        e1.record()
     return out
 
 

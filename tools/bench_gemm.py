@@ -39,7 +39,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=5)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--force-tile", type=int, default=0)
     a = ap.parse_args()
+    import ctypes
+    lib.vlb_gemm_set_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.vlb_gemm_set_variant.restype = None
+    lib.vlb_gemm_set_variant(a.variant, a.force_tile)
+    print(f"variant={a.variant} force_tile={a.force_tile}")
     Md = a.batch * 2048
     Mv = a.batch * 12 * 577
     shapes = [("dec qkv", Md, 6144, 4096), ("dec o", Md, 4096, 4096), ("dec gate_up", Md, 28672, 4096),
