@@ -184,14 +184,25 @@ int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, cons
                  float l2_lambda, float loss_scale, float l2_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * LoRA weight gradients (peft: only A,B train).  dW[N,K] (fp32, accumulate if beta!=0) =
- *   alpha * sum_m  G[m, n] * X[m, k]      G: [M,N] bf16 (ldg), X: [M,K] bf16 (ldx); N <= 64.
- * Used as dA = s*(dY B)^T X  (N=r) and dB^T = s*(X A^T)^T dY (N=r, K=out): both skinny-N.
- * ws: fp32 [vlb_wgrad_splits(M), N, K] partial slabs.
+ * LoRA adapters (peft LoraConfig(r, lora_alpha, lora_dropout) + get_peft_model, litmodule :113-120):
+ *   y = x W^T + s * B(A(dropout_p(x))),  s = alpha/r; only A [r,in] and B [out,r] train.
+ * The base GEMM carries the adapter through vlb_gemm_bf16's second operand pair (A2 = t, W2 = B).
+ * Dropout masks are counter-based hashes of (seed, row, column) - regenerated in backward, never
+ * stored; every 16-rank group (= one adapted projection) has its own seed (peft: one Dropout each).
  */
+/* t[M,R] = scale/(1-p) * keep(x) . A^T ; A: [R,K] bf16 (R = 16 * projections sharing x, <= 48);
+ * seeds_host: R/16 host uint32 (may be NULL when drop_p == 0). */
+int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M, int K, int R, float scale,
+                  float drop_p, const uint32_t* seeds_host, void* stream);
+/* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K,R] bf16 (transposed adapters). */
+int vlb_lora_dx_masked(const void* u, int ldu, const void* At, void* dx, int lddx, int M, int K, int R, float drop_p,
+                       const uint32_t* seeds_host, void* stream);
+/* Skinny weight gradient: dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep(X[m,k]) + beta * dW ; N <= 64.
+ * dA = s*(dY B)^T drop(x)  (G = dY.B, X = x) and dB^T = (s*drop(x) A^T)^T dY  (G = t, X = dY, p = 0).
+ * ws: fp32 [vlb_wgrad_splits(M), N, K] partial slabs (fixed-order sum: reproducible). */
 int vlb_wgrad_splits(int M);
 int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
-                     float alpha, float beta, void* stream);
+                     float alpha, float beta, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (litmodule :345-379 AdamW + CosineAnnealingLR; Trainer gradient_clip_val).

@@ -22,7 +22,7 @@ SIGNATURES = {
     "vlb_gemm_kernel_choice": [I, I, I, I],
     "vlb_transpose_bf16": [P, P, I, I, P],
     "vlb_attention_fwd": [P, I, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
-    # TODO(bwd) "vlb_attention_bwd": [P, I, P, I, P, I, P, I, P, I, P, P, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
+    "vlb_attention_bwd": [P, I, P, I, P, I, P, I, P, I, P, P, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
     "vlb_rmsnorm_fwd": [P, P, P, I, I, F, P],
     "vlb_rmsnorm_bwd": [P, P, P, P, P, I, I, F, P],
     "vlb_layernorm_fwd": [P, P, P, P, P, I, I, F, I, P],
@@ -43,8 +43,10 @@ SIGNATURES = {
     "vlb_head_ws_floats": [I, I, I, I],
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P],
-    # TODO(bwd) "vlb_wgrad_splits": [I],
-    # TODO(bwd) "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, P],
+    "vlb_wgrad_splits": [I],
+    "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, ctypes.c_uint32, P],
+    "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],
+    "vlb_lora_dx_masked": [P, I, P, P, I, I, I, I, F, P, P],
     "vlb_grad_sumsq": [P, L, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],

@@ -259,9 +259,38 @@ class Backbone:
         g = self.g
         return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag)
 
-    def decoder(self, x, key_mask, B, S, layer_outputs=None):
+    # ---------------- fsdp.yaml-equivalent sharding of the frozen decoder weights (opt-in)
+    SHARD_KEYS = ("wqkv", "wo", "wgu", "wdown")
+
+    def enable_sharding(self, group=None):
+        """Keep only this rank's 1/world shard of every decoder layer; full layers are all-gathered one
+        layer ahead of compute on a side stream (parallel.ShardedLayerStore)."""
+        from .parallel import ShardedLayerStore
+        side = torch.cuda.Stream(device=self.w.dev)
+        self.store = ShardedLayerStore(self.w.layers, self.SHARD_KEYS, group, stream=side)
+        self.store_t = None
+        if "wqkv_t" in self.w.layers[0]:
+            tkeys = tuple(k + "_t" for k in self.SHARD_KEYS)
+            self.store_t = ShardedLayerStore(self.w.layers, tkeys, group, stream=side)
         for lw in self.w.layers:
-            x = self.decoder_layer(x, lw, key_mask, B, S)
+            for k in list(lw):
+                if k in self.SHARD_KEYS or k.endswith("_t"):
+                    lw[k] = None
+        torch.cuda.empty_cache()
+
+    def layer_weights(self, i, transposed=False, direction=1):
+        """Weights of decoder layer i (gathered when sharded) and prefetch of the next one."""
+        lw = self.w.layers[i]
+        store = getattr(self, "store_t" if transposed else "store", None)
+        if store is None:
+            return lw
+        full = store.get(i)
+        store.prefetch(i + direction)
+        return {**lw, **full}
+
+    def decoder(self, x, key_mask, B, S, layer_outputs=None):
+        for i in range(len(self.w.layers)):
+            x = self.decoder_layer(x, self.layer_weights(i), key_mask, B, S)
             if layer_outputs is not None:
                 layer_outputs.append(x)
         return ops.rmsnorm(x, self.w.final_norm, self.g.rms_eps)

@@ -228,6 +228,8 @@ class VLBLitModule(_Base):
             bf16_copies.update(self.lora.compute_copies())
         self.optimizer = VlbAdamW(named, bf16_copies, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
                                   weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val)
+        if self.lora is not None:
+            self.optimizer.post_step.append(self.lora.refresh)
         self.lr_scheduler_args = {"last_epoch": cfg.last_epoch, "T_max": cfg.t_max}
         self.scheduler = getattr(torch.optim.lr_scheduler, cfg.lr_scheduler_name)(self.optimizer, **self.lr_scheduler_args)
         return [self.optimizer], [{"scheduler": self.scheduler, "interval": "step", "frequency": 1}]

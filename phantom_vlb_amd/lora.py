@@ -1,0 +1,253 @@
+"""LoRA fine-tuning of the decoder on libvlb: explicit forward-with-save and backward.
+
+What the reference gets from ``peft.get_peft_model(model, LoraConfig(task_type="FEATURE_EXTRACTION",
+r, lora_alpha, lora_dropout, target_modules=find_all_linear_names(model)))``
+(src/litmodule/videollama2_vlb_litmodule.py:36-55,113-120): every decoder linear
+``{q,k,v,o,gate,up,down}_proj`` becomes ``y = x W^T + (alpha/r) * B(A(dropout_p(x)))`` with W frozen,
+A kaiming-uniform(a=sqrt 5), B zero.  (peft matches target names by suffix, so upstream the CLIP
+``q_proj/k_proj/v_proj`` could be wrapped too; the tower is frozen and BASELINE.json says "LoRA on
+attn/MLP", so only the 7 decoder linears are adapted - SURVEY.md 7.2.)
+
+MI355X layout: projections that share an input share one skinny launch (q,k,v -> R=48; gate,up ->
+R=32); the adapter's up-projection rides in the base GEMM as a second operand pair (t | B), so
+adapted and base outputs are accumulated in the same MFMA accumulators; dgrad uses the transposed
+frozen weights laid down once at load time.  Masters are fp32 ``A [r,in]`` and ``B^T [r,out]``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+from .geometry import Geometry
+
+BF16 = torch.bfloat16
+PAD = 64  # adapter rank columns padded to one GEMM K-tile
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _seeds(vals):
+    return (ctypes.c_uint32 * len(vals))(*[v & 0xFFFFFFFF for v in vals])
+
+
+def lora_down(x, A, R, scale, p, seeds, out):
+    M, K = x.shape
+    check(lib.vlb_lora_down(x.data_ptr(), x.stride(0), A.data_ptr(), out.data_ptr(), out.stride(0), M, K, R, scale, p,
+                            _seeds(seeds) if p > 0 else None, _stream()), "vlb_lora_down")
+    return out
+
+
+def lora_dx_masked(u, At, dx, R, p, seeds):
+    M, K = dx.shape
+    check(lib.vlb_lora_dx_masked(u.data_ptr(), u.stride(0), At.data_ptr(), dx.data_ptr(), dx.stride(0), M, K, R, p,
+                                 _seeds(seeds), _stream()), "vlb_lora_dx_masked")
+
+
+def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seed=0):
+    M, K = X.shape
+    check(lib.vlb_wgrad_skinny(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), ws.data_ptr(), M, N, K,
+                               alpha, beta, p, seed & 0xFFFFFFFF, _stream()), "vlb_wgrad_skinny")
+
+
+# (group name, [(target, out rows attr)], input) - projections in one group share their input
+GROUPS = (
+    ("qkv", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj")),
+    ("o", ("self_attn.o_proj",)),
+    ("gu", ("mlp.gate_proj", "mlp.up_proj")),
+    ("down", ("mlp.down_proj",)),
+)
+
+
+class LoraState:
+    def __init__(self, g: Geometry, weights, r: int, alpha: int, dropout: float, device, seed: int = 1234,
+                 sd: dict | None = None):
+        assert r == 16, "kernels are specialised for r = 16 (the reference's lora_r)"
+        self.g, self.w, self.r, self.dev = g, weights, r, device
+        self.scale = alpha / r
+        self.p = float(dropout)
+        self.step = 0
+        self.base_seed = seed
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        self.out_dims = {"self_attn.q_proj": qd, "self_attn.k_proj": kd, "self_attn.v_proj": kd, "self_attn.o_proj": g.dim,
+                         "mlp.gate_proj": g.ff, "mlp.up_proj": g.ff, "mlp.down_proj": g.dim}
+        self.in_dims = {"self_attn.q_proj": g.dim, "self_attn.k_proj": g.dim, "self_attn.v_proj": g.dim,
+                        "self_attn.o_proj": qd, "mlp.gate_proj": g.dim, "mlp.up_proj": g.dim, "mlp.down_proj": g.ff}
+        gen = torch.Generator(device="cpu").manual_seed(seed + 17)
+        self.master: dict[str, torch.Tensor] = {}
+        self.grads: dict[str, torch.Tensor] = {}
+        self.layers = []
+        for i in range(g.layers):
+            lay = {}
+            for gname, targets in GROUPS:
+                R = 16 * len(targets)
+                kin = self.in_dims[targets[0]]
+                A = torch.zeros(R, kin, dtype=BF16, device=device)                 # stacked adapters (compute copy)
+                nout = sum(self.out_dims[t] for t in targets)
+                lay[gname] = dict(A=A, At=torch.zeros(kin, PAD, dtype=BF16, device=device),
+                                  Bpad=torch.zeros(nout, PAD, dtype=BF16, device=device), R=R, targets=targets)
+                for j, t in enumerate(targets):
+                    pre = f"model.layers.{i}.{t}"
+                    if sd is not None and f"{pre}.lora_A.weight" in sd:
+                        a0 = sd[f"{pre}.lora_A.weight"].float()
+                        b0 = sd[f"{pre}.lora_B.weight"].float().t().contiguous()
+                    else:
+                        bound = 1.0 / math.sqrt(kin)           # kaiming_uniform(a=sqrt(5))
+                        a0 = (torch.rand(16, kin, generator=gen) * 2 - 1) * bound
+                        b0 = torch.zeros(16, self.out_dims[t])
+                    self.master[f"{pre}.lora_A.weight"] = a0.to(device).contiguous()
+                    self.master[f"{pre}.lora_B.weight"] = b0.to(device).contiguous()    # stored as B^T [r,out]
+            self.layers.append(lay)
+        self.grads = {n: torch.zeros_like(t) for n, t in self.master.items()}
+        # bf16 compute copies the optimiser refreshes in place: A rows inside the stacked matrix, B^T separate
+        self.bt = {n: torch.zeros(t.shape, dtype=BF16, device=device) for n, t in self.master.items() if "lora_B" in n}
+        self.refresh(from_master=True)
+        self._ws = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def named_masters(self):
+        return list(self.master.items())
+
+    def compute_copies(self):
+        out = {}
+        for i, lay in enumerate(self.layers):
+            for gname, targets in GROUPS:
+                for j, t in enumerate(targets):
+                    pre = f"model.layers.{i}.{t}"
+                    out[f"{pre}.lora_A.weight"] = lay[gname]["A"][16 * j:16 * j + 16]
+                    out[f"{pre}.lora_B.weight"] = self.bt[f"{pre}.lora_B.weight"]
+        return out
+
+    def refresh(self, from_master=False):
+        """Rebuild the derived layouts (A^T padded, block-diagonal padded B) from the bf16 copies."""
+        cc = self.compute_copies()
+        for i, lay in enumerate(self.layers):
+            for gname, targets in GROUPS:
+                blk = lay[gname]
+                row = 0
+                for j, t in enumerate(targets):
+                    pre = f"model.layers.{i}.{t}"
+                    if from_master:
+                        cc[f"{pre}.lora_A.weight"].copy_(self.master[f"{pre}.lora_A.weight"])
+                        cc[f"{pre}.lora_B.weight"].copy_(self.master[f"{pre}.lora_B.weight"])
+                    n = self.out_dims[t]
+                    blk["Bpad"][row:row + n, 16 * j:16 * j + 16] = cc[f"{pre}.lora_B.weight"].t()
+                    row += n
+                blk["At"][:, :blk["R"]] = blk["A"].t()
+
+    def state_dict(self):
+        """peft layout: lora_A [r,in], lora_B [out,r]."""
+        return {n: (t.t().contiguous() if "lora_B" in n else t.clone()) for n, t in self.master.items()}
+
+    def _seed(self, layer, target_idx):
+        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA6B + layer * 0xC2B2AE35 + target_idx * 0x27D4EB2F) & 0xFFFFFFFF
+        return x or 1
+
+    def _workspace(self, M):
+        if self._ws is None or self._ws["M"] != M:
+            g, d = self.g, self.dev
+            kmax = max(g.ff, g.dim, g.heads * g.head_dim)
+            self._ws = dict(M=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 16 * kmax, dtype=torch.float32, device=d),
+                            u=torch.zeros(M, PAD, dtype=BF16, device=d))
+        return self._ws
+
+    # ------------------------------------------------------------------ forward with saved activations
+    def _adapted(self, x, W, blk, seeds, residual=None):
+        t = torch.zeros(x.shape[0], PAD, dtype=BF16, device=self.dev)
+        lora_down(x, blk["A"], blk["R"], self.scale, self.p, seeds, t)
+        return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
+
+    def forward(self, backbone, vision_f32, ids):
+        """Training forward of the whole backbone; decoder activations are kept for backward."""
+        g, w = self.g, self.w
+        B = vision_f32.shape[0]
+        S = g.max_len
+        pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
+        vid = backbone.connector(backbone.vision_tower(pix), B)          # frozen: no activations kept
+        x, key_mask = backbone.splice(ids, vid)
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        self.saved = []
+        self.step += 1
+        for li, lay in enumerate(self.layers):
+            lw = backbone.layer_weights(li)
+            sd = [self._seed(li, k) for k in range(7)]
+            h1 = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
+            qkv, t_qkv = self._adapted(h1, lw["wqkv"], lay["qkv"], sd[0:3])
+            ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim)
+            a, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads,
+                                       g.head_dim, True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True)
+            x2, t_o = self._adapted(a, lw["wo"], lay["o"], sd[3:4], residual=x)
+            h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
+            gu, t_gu = self._adapted(h2, lw["wgu"], lay["gu"], sd[4:6])
+            hh = ops.swiglu(gu)
+            x3, t_d = self._adapted(hh, lw["wdown"], lay["down"], sd[6:7], residual=x2)
+            self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh, t_qkv=t_qkv, t_o=t_o,
+                                   t_gu=t_gu, t_d=t_d, seeds=sd))
+            x = x3
+        self.x_last, self.key_mask, self.B = x, key_mask, B
+        return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
+
+    # ------------------------------------------------------------------ backward
+    def _group_backward(self, li, gname, dy, x_in, t, seeds, W_t, need_dx):
+        """dy: grad of the group's (concatenated) output; x_in: the group's input; returns d x_in."""
+        lay = self.layers[li][gname]
+        ws = self._workspace(dy.shape[0])
+        u = ws["u"]
+        col = 0
+        for j, tname in enumerate(lay["targets"]):
+            n = self.out_dims[tname]
+            pre = f"model.layers.{li}.{tname}"
+            dyj = dy[:, col:col + n]
+            # u_j = s * dy_j . B_j   (B^T [r,out] is exactly the [R,K] operand of the skinny kernel)
+            lora_down(dyj, self.bt[f"{pre}.lora_B.weight"], 16, self.scale, 0.0, None, u[:, 16 * j:16 * j + 16])
+            # dB^T[r,out] = sum_m t[m,r] dy[m,out]      (t carries s and 1/(1-p))
+            wgrad_skinny(t[:, 16 * j:16 * j + 16], dyj, self.grads[f"{pre}.lora_B.weight"], ws["wg"], 16)
+            # dA[r,in] = sum_m u[m,r] keep(x[m,in])/(1-p)
+            wgrad_skinny(u[:, 16 * j:16 * j + 16], x_in, self.grads[f"{pre}.lora_A.weight"], ws["wg"], 16, p=self.p,
+                         seed=seeds[j])
+            col += n
+        if not need_dx:
+            return None
+        if self.p == 0.0:
+            return ops.gemm(dy, W_t, a2=u, w2=lay["At"])
+        dx = ops.gemm(dy, W_t)
+        lora_dx_masked(u, lay["At"], dx, lay["R"], self.p, seeds)
+        return dx
+
+    def backward(self, backbone, dhidden):
+        """dhidden: d loss / d (post-final-norm hidden) bf16 [B*S, dim].  Fills self.grads."""
+        g, w = self.g, self.w
+        B, S = self.B, g.max_len
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        M = B * S
+        dx = ops.rmsnorm_bwd(self.x_last, w.final_norm, dhidden, g.rms_eps)
+        delta = torch.empty(B, g.heads, S, dtype=torch.float32, device=self.dev)
+        dq_acc = torch.empty(M, qd, dtype=torch.float32, device=self.dev)
+        for li in range(g.layers - 1, -1, -1):
+            lw, sv = backbone.layer_weights(li, transposed=True, direction=-1), self.saved[li]
+            sd = sv["seeds"]
+            d_hh = self._group_backward(li, "down", dx, sv["hh"], sv["t_d"], sd[6:7], lw["wdown_t"], True)
+            d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
+            d_h2 = self._group_backward(li, "gu", d_gu, sv["h2"], sv["t_gu"], sd[4:6], lw["wgu_t"], True)
+            dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
+            d_a = self._group_backward(li, "o", dx2, sv["a"], sv["t_o"], sd[3:4], lw["wo_t"], True)
+            qkv = sv["qkv"]
+            dqkv = torch.empty_like(qkv)
+            check(lib.vlb_attention_bwd(qkv.data_ptr(), qkv.stride(0), qkv[:, qd:].data_ptr(), qkv.stride(0),
+                                        qkv[:, qd + kd:].data_ptr(), qkv.stride(0), sv["a"].data_ptr(), sv["a"].stride(0),
+                                        d_a.data_ptr(), d_a.stride(0), sv["lse"].data_ptr(), self.key_mask.data_ptr(),
+                                        dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
+                                        dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), dq_acc.data_ptr(),
+                                        B, S, g.heads, g.kv_heads, g.head_dim, 1, g.head_dim ** -0.5, _stream()),
+                  "vlb_attention_bwd")
+            ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1)
+            need_dx = li > 0                # embeddings / connector are frozen: nothing upstream of layer 0 trains
+            d_h1 = self._group_backward(li, "qkv", dqkv, sv["h1"], sv["t_qkv"], sd[0:3], lw["wqkv_t"], need_dx)
+            if need_dx:
+                dx = ops.rmsnorm_bwd(sv["x"], lw["in_norm"], d_h1, g.rms_eps, dx_in=dx2)
+        self.saved = []

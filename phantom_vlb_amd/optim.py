@@ -34,6 +34,7 @@ class VlbAdamW(torch.optim.Optimizer):
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=params[0].device)
         self.step_count = 0
         self.grad_reducer = None      # set by the data-parallel wrapper: callable(list_of_grads)
+        self.post_step = []           # callables run after every update (e.g. LoRA derived layouts)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -55,6 +56,8 @@ class VlbAdamW(torch.optim.Optimizer):
                                      v.data_ptr(), p.numel(), float(group["lr"]), float(b1), float(b2),
                                      float(group["eps"]), float(group["weight_decay"]), self.step_count,
                                      self.sumsq.data_ptr(), self.max_norm, st), "vlb_adamw_step")
+        for fn in self.post_step:
+            fn()
         return loss
 
     def grad_norm(self) -> float:

@@ -1,0 +1,157 @@
+"""Multi-GPU: one process per GPU, torch.distributed over RCCL/xGMI ("nccl" backend on ROCm).
+
+The path shards over CLIPS: every rank runs the same step on its own clips; the
+only exchange per optimiser step is the gradient of the trainables.  The reference has no
+multi-GPU mainline - only an unused Accelerate FSDP config (``fsdp.yaml``: FULL_SHARD,
+TRANSFORMER_BASED_WRAP on the decoder layer, BACKWARD_PRE, forward prefetch) - so this module is
+the MI355X-native equivalent of that config, not a translation of torch FSDP:
+
+* ``FlatGradReducer``  - all trainable gradients live in ONE flat fp32 buffer, reduced by a single
+  all-reduce per step (head: 8.4 M floats; +41.9 M with LoRA).  The frozen 7B never enters a
+  collective: with ``use_orig_params`` torch FSDP would reduce-scatter 436 MB per layer of zeros.
+  Loss scaling: each rank backpropagates mse/world and lambda||W||^2/world, so the SUM over ranks is
+  the gradient of the single-process objective on the concatenated batch (penalty counted once).
+* ``ShardedLayerStore`` - the fsdp.yaml-equivalent parameter sharding for the frozen decoder layers:
+  each rank keeps 1/world of every layer's flat bf16 weights (436 MB/layer -> 54.5 MB at 8 ranks);
+  the full layer is all-gathered into one of two buffers on a side stream, one layer ahead of
+  compute (forward and, in reverse order, backward).  On xGMI (point-to-point links) RCCL's
+  all-gather moves each 54.5 MB shard over its own link, ~0.36 ms/layer, hidden behind ~2 ms of
+  layer compute.  With 288 GB of HBM the replicated variant (no gathers) is the faster default;
+  sharding is opt-in (``shard_frozen=True``) for memory parity with the reference's FSDP intent.
+
+Everything here works on CPU tensors with the gloo backend (tests/test_cpu_parallel.py).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*). Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def dp_loss_scales(world: int):
+    """(mse gradient scale, ridge-penalty gradient scale) each rank applies before the SUM all-reduce."""
+    return 1.0 / world, 1.0 / world
+
+
+class FlatGradReducer:
+    """Re-points a set of gradient tensors into one flat buffer and all-reduces it in one call."""
+
+    def __init__(self, grad_dicts: list[dict], group=None):
+        self.group = group
+        items = [(d, k) for d in grad_dicts for k in d]
+        total = sum(d[k].numel() for d, k in items)
+        ref = items[0][0][items[0][1]]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for d, k in items:
+            n = d[k].numel()
+            view = self.flat[off:off + n].view(d[k].shape)
+            view.copy_(d[k])
+            d[k] = view                     # kernels write straight into the bucket from now on
+            off += n
+
+    def __call__(self, grads=None):
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def attach_data_parallel(module, optimizer, group=None):
+    """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism."""
+    dicts = [module.head.grads]
+    if getattr(module, "lora", None) is not None:
+        dicts.append(module.lora.grads)
+    reducer = FlatGradReducer(dicts, group)
+    optimizer.grad_reducer = reducer
+    module.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    module.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    return reducer
+
+
+def broadcast_parameters(tensors, src: int = 0, group=None):
+    """fsdp_sync_module_states equivalent: make every rank start from rank `src`'s trainables."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=group)
+
+
+class ShardedLayerStore:
+    """1/world shard of every layer's flat weights + double-buffered, prefetched all-gather."""
+
+    def __init__(self, layers: list[dict], keys: tuple, group=None, stream=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.keys = keys
+        self.meta = []          # per layer: [(key, shape, offset, numel)]
+        self.shards = []
+        maxpad = 0
+        for lw in layers:
+            off, meta = 0, []
+            for k in keys:
+                n = lw[k].numel()
+                meta.append((k, tuple(lw[k].shape), off, n))
+                off += (n + 7) // 8 * 8            # keep every tensor 16-byte aligned inside the flat layer
+            pad = (off + self.world * 8 - 1) // (self.world * 8) * (self.world * 8)
+            flat = torch.zeros(pad, dtype=lw[keys[0]].dtype, device=lw[keys[0]].device)
+            for k, shp, o, n in meta:
+                flat[o:o + n] = lw[k].reshape(-1)
+            per = pad // self.world
+            self.shards.append(flat[self.rank * per:(self.rank + 1) * per].clone())
+            self.meta.append((meta, pad))
+            maxpad = max(maxpad, pad)
+        dev = self.shards[0].device
+        self.buf = [torch.empty(maxpad, dtype=self.shards[0].dtype, device=dev) for _ in range(2)]
+        self.stream = stream
+        self.events = [None, None]
+        self.in_buf = [None, None]
+
+    def shard_bytes(self):
+        return sum(s.numel() * s.element_size() for s in self.shards)
+
+    def prefetch(self, i: int):
+        """Start gathering layer i into buffer i%2 (on the side stream when one was given)."""
+        if i < 0 or i >= len(self.shards) or self.in_buf[i % 2] == i:
+            return
+        b = i % 2
+        pad = self.meta[i][1]
+        out = self.buf[b][:pad]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())   # the buffer's previous consumer must be done
+            with torch.cuda.stream(self.stream):
+                self._gather(out, self.shards[i])
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self.events[b] = ev
+        else:
+            self._gather(out, self.shards[i])
+        self.in_buf[b] = i
+
+    def _gather(self, out, shard):
+        if self.world == 1:
+            out.copy_(shard)
+        else:
+            dist.all_gather_into_tensor(out, shard, group=self.group)
+
+    def get(self, i: int) -> dict:
+        """Full weights of layer i as views into the gather buffer (valid until layer i+2 is fetched)."""
+        self.prefetch(i)
+        b = i % 2
+        if self.stream is not None and self.events[b] is not None:
+            torch.cuda.current_stream().wait_event(self.events[b])
+        meta, _ = self.meta[i]
+        return {k: self.buf[b][o:o + n].view(shp) for k, shp, o, n in meta}

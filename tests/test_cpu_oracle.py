@@ -1,0 +1,172 @@
+"""CPU tier (-m "not gpu"): the oracle against its committed golden vectors, host logic, and the
+C-ABI surface (the library loads and exports every symbol include/vlb.h declares - no compute)."""
+import ctypes
+import hashlib
+import math
+import os
+import re
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _digest(p):
+    h = hashlib.sha256()
+    for k in sorted(p):
+        h.update(k.encode())
+        h.update(p[k].contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_oracle_reproduces_frozen_golden():
+    """Same seeds -> same weights (sha256), same inputs, same loss / prediction / head gradients."""
+    import vlb_oracle as O
+    g = O.geometry_mini()
+    gold = np.load(os.path.join(GOLD, "mini_frozen.npz"))
+    p = O.round_bf16(O.init_params(g, seed=1234))
+    assert _digest(p) == str(gold["weights_sha256"])
+    batch = O.synthetic_batch(g, 4, seed=1234)
+    assert np.array_equal(batch["language"].numpy(), gold["language"])
+    assert np.array_equal(batch["padvals"].numpy(), gold["padvals"])
+    names = O.trainable_names(p, True, False)
+    for n in names:
+        p[n].requires_grad_(True)
+    stages = {}
+    loss, pred = O.training_loss(p, batch, g, stages=stages)
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss"])) < 1e-6
+    assert np.allclose(pred.detach().numpy(), gold["pred"], atol=1e-5)
+    assert np.allclose(stages["hidden"].detach().numpy(), gold["hidden"], atol=1e-4)
+    assert np.allclose(stages["weight_mask"].numpy(), gold["weight_mask"])
+    for n in names:
+        assert np.allclose(p[n].grad.numpy(), gold["grad::" + n], atol=1e-6), n
+
+
+def test_oracle_lora_golden_loss_and_norm():
+    import vlb_oracle as O
+    g = O.geometry_mini()
+    gold = np.load(os.path.join(GOLD, "mini_lora.npz"))
+    p = O.round_bf16(O.init_params(g, seed=1234, lora=True, lora_b_std=0.02))
+    assert _digest(p) == str(gold["weights_sha256"])
+    batch = O.synthetic_batch(g, 4, seed=1234)
+    names = O.trainable_names(p, False, True)
+    assert len(names) == 6 + 2 * 7 * g.layers
+    for n in names:
+        p[n].requires_grad_(True)
+    loss, _ = O.training_loss(p, batch, g)
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss"])) < 1e-6
+    tot = math.sqrt(sum(float(p[n].grad.double().pow(2).sum()) for n in names))
+    assert abs(tot - float(gold["grad_global_norm"])) / tot < 1e-5
+
+
+def test_weight_mask_known_answers():
+    import vlb_oracle as O
+    kat = np.load(os.path.join(GOLD, "weight_mask_kat.npz"))
+    for i in range(4):
+        row = O.make_weight_mask(torch.from_numpy(kat[f"{i}_padvals"]), torch.from_numpy(kat[f"{i}_vis"]),
+                                 torch.from_numpy(kat[f"{i}_lang"]), 17, 20, tokens_per_frame=2)[0]
+        assert np.allclose(row.numpy(), kat[f"{i}_row"])
+    # hand-written case: 2 frames x 2 tokens, inst 1, dialog 3, no pad -> tail = 4 + 3 + 3 + 4 = 14
+    row = O.make_weight_mask(torch.tensor([[0, 1, 3]]), torch.tensor([[0.5, 0.25]], dtype=torch.float64),
+                             torch.tensor([[0.1, 0.2, 0.3, 0, 0, 0, 0, 0]], dtype=torch.float64), 17, 20, 2)[0]
+    assert row.tolist() == [0] * 6 + [0.5, 0.5, 0.25, 0.25] + [0] * 3 + [np.float32(0.1), np.float32(0.2), np.float32(0.3)] + [0] * 4
+
+
+def test_geometry_identities():
+    """The shape asserts the reference relies on (litmodule :180-181; lazyloading.py:104-108)."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.geometry import geometry_7b, geometry_mini
+    g = geometry_7b()
+    assert (g.ds_frames, g.ds_grid, g.vis_tokens, g.lang_len) == (7, 13, 1183, 866)
+    assert g.vis_tokens + g.lang_len - 1 == g.max_len == 2048
+    assert g.patch_k == 588 and g.patch_k_padded == 640 and g.vit_layers_run == 23
+    m = geometry_mini()
+    assert (m.ds_frames, m.ds_grid, m.vis_tokens, m.lang_len) == (5, 4, 80, 49)
+    for a, b in ((g, O.geometry_7b()), (m, O.geometry_mini())):
+        for f in ("vis_tokens", "lang_len", "ds_frames", "ds_grid", "vit_layers_run", "dim", "ff", "heads", "kv_heads"):
+            assert getattr(a, f) == getattr(b, f)
+
+
+def test_synthetic_batch_schema():
+    import vlb_oracle as O
+    from phantom_vlb_amd.geometry import geometry_mini
+    from phantom_vlb_amd.synthetic import synthetic_batch
+    g = geometry_mini()
+    b = synthetic_batch(g, 3, seed=9)
+    o = O.synthetic_batch(O.geometry_mini(), 3, seed=9)
+    assert {k: (v.shape, v.dtype) for k, v in b.items()} == {k: (v.shape, v.dtype) for k, v in o.items()}
+    assert b["vision"].shape == (3, 8, 3, 84, 84) and b["vision"].dtype == torch.float32
+    assert b["language"].shape == (3, 49) and b["padvals"].dtype == torch.int64
+    assert b["vis_weights"].dtype == torch.float64 and b["lang_weights"].shape == (3, 64)
+    for i in range(3):
+        assert int((b["language"][i] == -201).sum()) == 1
+        pad = int(b["padvals"][i, 0])
+        assert (b["language"][i, 49 - pad:] == 0).all() and (b["language"][i, :49 - pad] != 0).all()
+
+
+def test_optimizer_closed_forms_match_torch():
+    import vlb_oracle as O
+    torch.manual_seed(0)
+    p0, g0 = torch.randn(50), torch.randn(50)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50000)
+    m = v = torch.zeros(50)
+    cur = p0.clone()
+    for step in range(1, 4):
+        p.grad = g0 * step
+        lr = opt.param_groups[0]["lr"]
+        assert abs(lr - O.cosine_lr(1e-4, step - 1, 50000)) < 1e-12
+        opt.step()
+        sch.step()
+        cur, m, v = O.adamw_step(cur, g0 * step, m, v, step, lr)
+        assert torch.allclose(p.detach(), cur, atol=1e-7)
+    clipped, total = O.clip_grad_norm({"a": g0.clone()}, 1.0)
+    ref = g0.clone()
+    torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(ref)], 1.0)
+    assert abs(float(clipped["a"].norm()) - 1.0) < 1e-4 and abs(float(total) - float(g0.norm())) < 1e-5
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "vlb.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vlb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    """dlopen only - no kernel is launched without a GPU."""
+    from phantom_vlb_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vlb.h but not exported by libvlb.so"
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+    assert _lib.lib.vlb_abi_version() == 1
+    assert _lib.lib.vlb_gemm_kernel_choice(10240, 4096, 4096, 0) == 1
+    assert _lib.lib.vlb_gemm_kernel_choice(5, 2048, 4096, 0) == 0
+    assert _lib.lib.vlb_head_partial_rows(2048) == 64
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is the checker: nothing under phantom_vlb_amd/ (or train.py / src/) may reference it."""
+    bad = []
+    for base in ("phantom_vlb_amd", "src"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                    t = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(import|from)\s+(vlb_oracle|oracle)\b", t, flags=re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_ops_refuse_cpu_tensors():
+    from phantom_vlb_amd import ops
+    import pytest
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))

@@ -1,0 +1,257 @@
+"""LoRA path: adapter kernels, attention backward, and the mini LoRA training step vs goldens (-m gpu)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- numpy restatement of the kernels' counter-based dropout mask (phantom_vlb_amd/csrc/lora.hip)
+def _lowbias32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def keep_mask(seed, M, K, p):
+    thresh = min(65535, int(p * 65536 + 0.5))
+    m = np.arange(M, dtype=np.uint64)[:, None]
+    kp = np.arange(K // 2, dtype=np.uint64)[None, :]
+    c = m * np.uint64(K // 2) + kp
+    h = _lowbias32((c & np.uint64(0xffffffff)) ^ _lowbias32(((c >> np.uint64(32)) + np.uint64(seed)) & np.uint64(0xffffffff)))
+    keep = np.empty((M, K), dtype=bool)
+    keep[:, 0::2] = (h & np.uint64(0xffff)) >= thresh
+    keep[:, 1::2] = (h >> np.uint64(16)) >= thresh
+    return torch.from_numpy(keep)
+
+
+def _r(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev)
+
+
+@pytest.mark.parametrize("G,p", [(1, 0.0), (3, 0.0), (2, 0.1), (3, 0.25)])
+def test_lora_down(dev, G, p):
+    from phantom_vlb_amd.lora import lora_down
+    M, K, R = 200, 256, 16 * G
+    x, A = _r(M, K, dev=dev), _r(R, K, dev=dev, scale=0.1)
+    seeds = [11 + 7 * g for g in range(G)]
+    out = torch.zeros(M, 64, dtype=BF, device=dev)
+    lora_down(x, A, R, 2.0, p, seeds, out)
+    ref = torch.zeros(M, R)
+    for g in range(G):
+        xm = x.float().cpu()
+        if p > 0:
+            xm = xm * keep_mask(seeds[g], M, K, p) / (1 - p)
+        ref[:, 16 * g:16 * g + 16] = 2.0 * xm @ A[16 * g:16 * g + 16].float().cpu().t()
+    assert rel_err(out[:, :R], ref) < 8e-3
+    assert (out[:, R:] == 0).all()
+
+
+def test_dropout_mask_statistics(dev):
+    """keep-rate of the counter-based mask, measured through the kernel itself (x = 1, A = 1)."""
+    from phantom_vlb_amd.lora import lora_down
+    M, K, p = 4096, 4096, 0.1
+    x = torch.ones(M, K, dtype=BF, device=dev)
+    A = torch.zeros(16, K, dtype=BF, device=dev)
+    A[0] = 1
+    out = torch.zeros(M, 64, dtype=BF, device=dev)
+    lora_down(x, A, 16, 1.0, p, [12345], out)
+    kept_per_row = out[:, 0].float().cpu() * (1 - p)                     # = number of kept columns
+    rate = float(kept_per_row.sum()) / (M * K)
+    assert abs(rate - 0.9) < 2e-3
+    # rows are independent: the per-row keep count has binomial spread
+    std = float(kept_per_row.std())
+    assert 0.7 * math.sqrt(K * 0.09) < std < 1.5 * math.sqrt(K * 0.09) + 16   # bf16 rounding of the count adds noise
+    # a different seed gives a different mask
+    out2 = torch.zeros(M, 64, dtype=BF, device=dev)
+    lora_down(x, A, 16, 1.0, p, [54321], out2)
+    assert (out2[:, 0] != out[:, 0]).float().mean() > 0.5
+
+
+@pytest.mark.parametrize("G,p", [(1, 0.1), (3, 0.1), (2, 0.0)])
+def test_lora_dx_masked(dev, G, p):
+    from phantom_vlb_amd.lora import lora_dx_masked
+    M, K, R = 100, 1536, 16 * G
+    u = torch.zeros(M, 64, dtype=BF, device=dev)
+    u[:, :R] = _r(M, R, dev=dev)
+    A = _r(R, K, dev=dev, scale=0.1)
+    At = torch.zeros(K, 64, dtype=BF, device=dev)
+    At[:, :R] = A.t()
+    dx0 = _r(M, K, dev=dev, seed=5)
+    dx = dx0.clone()
+    seeds = [3 + g for g in range(G)]
+    lora_dx_masked(u, At, dx, R, p, seeds)
+    ref = dx0.float().cpu()
+    for g in range(G):
+        term = u[:, 16 * g:16 * g + 16].float().cpu() @ A[16 * g:16 * g + 16].float().cpu()
+        if p > 0:
+            term = term * keep_mask(seeds[g], M, K, p) / (1 - p)
+        ref = ref + term
+    assert rel_err(dx, ref) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,p", [(300, 16, 512, 0.0), (1000, 16, 1024, 0.1), (64, 16, 4096, 0.0)])
+def test_wgrad_skinny(dev, M, N, K, p):
+    from phantom_vlb_amd._lib import lib
+    from phantom_vlb_amd.lora import wgrad_skinny
+    Gm = torch.zeros(M, 64, dtype=BF, device=dev)
+    Gm[:, 16:32] = _r(M, N, dev=dev)
+    X = _r(M, K + 64, dev=dev, seed=2)[:, :K]                 # strided view
+    dW = torch.full((N, K), 7.0, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.vlb_wgrad_splits(M) * N * K, dtype=torch.float32, device=dev)
+    wgrad_skinny(Gm[:, 16:32], X, dW, ws, N, alpha=0.5, beta=0.0, p=p, seed=99)
+    xm = X.float().cpu()
+    if p > 0:
+        xm = xm * keep_mask(99, M, K, p) / (1 - p)
+    ref = 0.5 * Gm[:, 16:32].float().cpu().t() @ xm
+    assert rel_err(dW, ref) < 2e-3
+    wgrad_skinny(Gm[:, 16:32], X, dW, ws, N, alpha=0.5, beta=1.0, p=p, seed=99)     # accumulate
+    assert rel_err(dW, 2 * ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,causal,masked", [(2, 128, 4, 1, True, True), (1, 300, 8, 2, True, False),
+                                                     (2, 96, 2, 2, False, False), (1, 1024, 4, 1, True, True)])
+def test_attention_bwd(dev, B, S, Hq, Hkv, causal, masked):
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd._lib import check, lib
+    D = 128
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(B * S, (Hq + 2 * Hkv) * D, generator=g) * 0.7).to(BF)
+    dout = torch.randn(B * S, Hq * D, generator=g).to(BF)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.uint8)
+        mask[0, S - S // 4:] = 0
+    qd, kd = Hq * D, Hkv * D
+    # reference: autograd through the fp32 definition
+    q = qkv[:, :qd].float().view(B, S, Hq, D).requires_grad_(True)
+    k = qkv[:, qd:qd + kd].float().view(B, S, Hkv, D).requires_grad_(True)
+    v = qkv[:, qd + kd:].float().view(B, S, Hkv, D).requires_grad_(True)
+    rep = Hq // Hkv
+    s = q.transpose(1, 2) @ k.transpose(1, 2).repeat_interleave(rep, 1).transpose(2, 3) * D ** -0.5
+    allow = torch.ones(B, 1, S, S, dtype=torch.bool)
+    if causal:
+        allow = allow & torch.ones(S, S, dtype=torch.bool).tril()
+    if mask is not None:
+        allow = allow & mask.bool()[:, None, None, :]
+    o = (torch.softmax(s.masked_fill(~allow, float("-inf")), -1) @ v.transpose(1, 2).repeat_interleave(rep, 1)).transpose(1, 2)
+    valid = torch.ones(B, S, 1, 1) if mask is None else mask.float()[:, :, None, None]
+    (o * dout.float().view(B, S, Hq, D) * valid).sum().backward()      # padded query rows carry no gradient
+    dq_ref, dk_ref, dv_ref = q.grad, k.grad, v.grad
+
+    dq_ = qkv.to(dev)
+    dmask = None if mask is None else mask.to(dev)
+    dout_d = (dout.float().view(B, S, Hq, D) * valid).to(BF).view(B * S, Hq * D).to(dev)
+    out, lse = ops.attention_fwd(dq_[:, :qd], dq_[:, qd:qd + kd], dq_[:, qd + kd:], B, S, Hq, Hkv, D, causal, D ** -0.5,
+                                 key_mask=dmask, need_lse=True)
+    dqkv = torch.zeros_like(dq_)
+    delta = torch.empty(B, Hq, S, dtype=torch.float32, device=dev)
+    acc = torch.empty(B * S, qd, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.vlb_attention_bwd(dq_.data_ptr(), dq_.stride(0), dq_[:, qd:].data_ptr(), dq_.stride(0),
+                                dq_[:, qd + kd:].data_ptr(), dq_.stride(0), out.data_ptr(), out.stride(0),
+                                dout_d.data_ptr(), dout_d.stride(0), lse.data_ptr(), None if dmask is None else dmask.data_ptr(),
+                                dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
+                                dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), acc.data_ptr(), B, S, Hq, Hkv,
+                                D, 1 if causal else 0, D ** -0.5, st), "bwd")
+    got = dqkv.float().cpu()
+    assert rel_err(got[:, :qd].view(B, S, Hq, D), dq_ref) < 2e-2
+    assert rel_err(got[:, qd:qd + kd].view(B, S, Hkv, D), dk_ref) < 2e-2
+    assert rel_err(got[:, qd + kd:].view(B, S, Hkv, D), dv_ref) < 2e-2
+
+
+def _lora_cfg(p=0.0):
+    from phantom_vlb_amd.litmodule import VLBLitModuleConfig
+    return VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=True, lora_r=16, lora_alpha=32,
+                              lora_dropout=p, dropout_rate=0.0, num_target=128, l2_lambda=1e-3, lr=1e-4,
+                              betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR",
+                              last_epoch=-1, t_max=50000, geometry="mini")
+
+
+def test_mini_lora_training_step_vs_golden(dev):
+    """configs[0] with LoRA (B != 0 so every gradient path is live), dropout off: loss, pred, head and
+    adapter gradients against the committed goldens."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.lora import LoraState
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=1234, lora=True, lora_b_std=0.02))
+    batch = O.synthetic_batch(g, 4, seed=1234)
+    gold = np.load(os.path.join(GOLD, "mini_lora.npz"))
+    m = VLBLitModule(_lora_cfg())
+    m.configure_model(state_dict=p, head_state=p)
+    m.lora = LoraState(m.geometry, m.backbone.w, 16, 32, 0.0, m.device, sd=p)
+    m.configure_optimizers()
+    loss = m.training_step(batch)
+    assert abs(float(loss) - float(gold["loss"])) / float(gold["loss"]) < 1e-3
+    assert rel_err(m.head.pred, torch.from_numpy(gold["pred"])) < 3e-2
+    checked = 0
+    for name in gold.files:
+        if not name.startswith("grad::"):
+            continue
+        n = name[len("grad::"):]
+        ref = torch.from_numpy(gold[name])
+        if ".lora_" in n:
+            got = m.lora.grads[n]
+            if "lora_B" in n:
+                got = got.t()
+        else:
+            got = m.head.grads[n]
+        assert rel_err(got, ref) < 6e-2, n
+        checked += 1
+    assert checked >= 6 + 28
+    # global gradient norm (what the clip sees)
+    tot = math.sqrt(sum(float(t.double().pow(2).sum()) for t in list(m.head.grads.values()) + list(m.lora.grads.values())))
+    assert abs(tot - float(gold["grad_global_norm"])) / float(gold["grad_global_norm"]) < 3e-2
+    # optimiser step refreshes the derived adapter layouts
+    opt = m.optimizer
+    a_before = m.lora.layers[0]["qkv"]["At"].clone()
+    opt.step()
+    assert not torch.equal(a_before, m.lora.layers[0]["qkv"]["At"])
+    assert torch.equal(m.lora.layers[0]["qkv"]["At"][:, :48], m.lora.layers[0]["qkv"]["A"].t())
+
+
+def test_mini_lora_dropout_matches_oracle(dev):
+    """LoRA dropout 0.1: the oracle is fed the SAME counter-based masks (restated in numpy)."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.lora import GROUPS, LoraState
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=5, lora=True, lora_b_std=0.05))
+    batch = O.synthetic_batch(g, 2, seed=6)
+    m = VLBLitModule(_lora_cfg(0.1))
+    m.configure_model(state_dict=p, head_state=p)
+    m.lora = LoraState(m.geometry, m.backbone.w, 16, 32, 0.1, m.device, sd=p)
+    m.configure_optimizers()
+    loss = m.training_step(batch)
+    # rebuild the masks the kernels used (step counter is 1 after the first forward)
+    M = 2 * g.max_len
+    drop = {}
+    for li in range(g.layers):
+        idx = 0
+        for gname, targets in GROUPS:
+            for t in targets:
+                seed = m.lora._seed(li, idx)
+                K = m.lora.in_dims[t]
+                drop[f"model.layers.{li}.{t}"] = (keep_mask(seed, M, K, 0.1).float() / 0.9).view(2, g.max_len, K)
+                idx += 1
+    names = O.trainable_names(p, False, True)
+    pr = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
+    loss_ref, _ = O.training_loss(pr, batch, g, lora_drop=drop)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 1e-3
+    for n in ("model.layers.0.self_attn.q_proj.lora_A.weight", "model.layers.1.mlp.down_proj.lora_A.weight",
+              "model.layers.0.mlp.up_proj.lora_B.weight", "model.layers.1.self_attn.v_proj.lora_B.weight"):
+        got = m.lora.grads[n].t() if "lora_B" in n else m.lora.grads[n]
+        assert rel_err(got, pr[n].grad) < 6e-2, n
