@@ -194,8 +194,8 @@ int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, cons
  * seeds_host: R/16 host uint32 (may be NULL when drop_p == 0). */
 int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M, int K, int R, float scale,
                   float drop_p, const uint32_t* seeds_host, void* stream);
-/* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K,R] bf16 (transposed adapters). */
-int vlb_lora_dx_masked(const void* u, int ldu, const void* At, void* dx, int lddx, int M, int K, int R, float drop_p,
+/* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K, >=R] bf16 (transposed adapters, row stride ldat). */
+int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
                        const uint32_t* seeds_host, void* stream);
 /* Skinny weight gradient: dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep(X[m,k]) + beta * dW ; N <= 64.
  * dA = s*(dY B)^T drop(x)  (G = dY.B, X = x) and dB^T = (s*drop(x) A^T)^T dY  (G = t, X = dY, p = 0).

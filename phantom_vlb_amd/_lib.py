@@ -46,7 +46,7 @@ SIGNATURES = {
     "vlb_wgrad_splits": [I],
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, ctypes.c_uint32, P],
     "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],
-    "vlb_lora_dx_masked": [P, I, P, P, I, I, I, I, F, P, P],
+    "vlb_lora_dx_masked": [P, I, P, I, P, I, I, I, I, F, P, P],
     "vlb_grad_sumsq": [P, L, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],

@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16* __restrict__
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16* xr = x + (int64_t)m * ldx + fq * 8;
-#pragma unroll 2
   for (int k0 = 0; k0 < K; k0 += 32) {
     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + k0);
 #pragma unroll
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16* __restrict__
 // At[K][R] is the transposed adapter (row = input column).  One wave = 16 rows x 16 columns per MFMA;
 // a wave walks 16 rows x 256 columns.
 template <int G>
-__global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u, int ldu, const bf16* __restrict__ At, int R,
+__global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u, int ldu, const bf16* __restrict__ At, int ldat,
                                                       bf16* __restrict__ dx, int lddx, int M, int K, float inv_keep,
                                                       uint32_t thresh, Seeds seeds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       bf16x8 af = bf16x8{};
-      if (fq < 2) af = *reinterpret_cast<const bf16x8*>(At + (int64_t)(kcol + fr) * R + 16 * g + 8 * fq);
+      if (fq < 2) af = *reinterpret_cast<const bf16x8*>(At + (int64_t)(kcol + fr) * ldat + 16 * g + 8 * fq);
       f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, uf[g], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       // lane holds columns kcol + 4fq + {0..3} of row m0 + fr
       if (thresh != 0) {
@@ -259,10 +258,10 @@ extern "C" int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int
   return VLB_OK;
 }
 
-extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, void* dx, int lddx, int M, int K, int R,
+extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R,
                                   float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(u && At && dx, "lora_dx_masked: null operand");
-  VLB_REQUIRE(M > 0 && K % 16 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldu % 8 == 0 && lddx % 4 == 0,
+  VLB_REQUIRE(M > 0 && K % 16 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldu % 8 == 0 && lddx % 4 == 0 && ldat % 8 == 0 && ldat >= R,
               "lora_dx_masked: bad shape M=%d K=%d R=%d", M, K, R);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "lora_dx_masked: bad dropout arguments");
   Seeds s{};
@@ -272,9 +271,9 @@ extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, void* 
   const uint32_t th = thresh16(drop_p);
   const float ik = 1.f / (1.f - drop_p);
   switch (R / 16) {
-    case 1: hipLaunchKernelGGL(lora_dx_kernel<1>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, R, (bf16*)dx, lddx, M, K, ik, th, s); break;
-    case 2: hipLaunchKernelGGL(lora_dx_kernel<2>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, R, (bf16*)dx, lddx, M, K, ik, th, s); break;
-    default: hipLaunchKernelGGL(lora_dx_kernel<3>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, R, (bf16*)dx, lddx, M, K, ik, th, s); break;
+    case 1: hipLaunchKernelGGL(lora_dx_kernel<1>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
+    case 2: hipLaunchKernelGGL(lora_dx_kernel<2>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
+    default: hipLaunchKernelGGL(lora_dx_kernel<3>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
   }
   VLB_LAUNCH_CHECK();
   return VLB_OK;

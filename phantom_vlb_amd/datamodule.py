@@ -1,0 +1,166 @@
+"""Mirror of the reference's ``src.datamodule`` (VLBDataModule, VLBDataModuleConfig, VLB_Dataset,
+VLBDatasets; src/datamodule/videollama2_vlb_datamodule.py:24-238).
+
+Same sample schema (6 arrays per sample: timeseries, vision, language as fp32 tensors; padvals,
+vis_weights, lang_weights as numpy), same file-level train/val split (one random file is the
+validation set, ``np.random.RandomState(random_state).choice``), same ``$SCRATCH_PATH`` /
+``s*`` -> season substitution, same DataLoader settings.  Two additions because this environment
+has neither h5py nor the CNeuroMod files:
+  * ``.npz`` lazy-load files with the same keys (``{i}_{mod}`` + ``dset_len``) are read when h5py is
+    absent (tools/h5_to_npz.py converts on a machine that has h5py);
+  * ``lazyload_path: synthetic:<n_files>x<samples>`` yields seeded synthetic samples.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+try:
+    from lightning.pytorch import LightningDataModule as _Base  # type: ignore
+except Exception:  # pragma: no cover
+    class _Base:
+        def __init__(self):
+            pass
+
+MODS_T = ("timeseries", "vision", "language")
+MODS_N = ("padvals", "vis_weights", "lang_weights")
+
+
+def get_idx(ranges, val):
+    for i, (lo, hi) in enumerate(ranges):
+        if lo <= val < hi:
+            return i
+    return -1
+
+
+@dataclass
+class VLBDataModuleConfig:
+    lazyload_path: str
+    subject: str
+    seasons: list
+    delay: int
+    window: int
+    random_state: int
+    shuffle_val_data: bool
+    batch_size: int = 1
+    num_workers: int = 0
+    # extras
+    geometry: str = "7b"
+    num_target: int = 1000
+
+
+class _H5File:
+    def __init__(self, path):
+        import h5py
+        self.f = h5py.File(path, "r")
+        self.length = int(np.array(self.f["dset_len"])[0])
+
+    def get(self, i, mod):
+        return np.array(self.f[f"{i}"][f"{i}_{mod}"])
+
+
+class _NpzFile:
+    def __init__(self, path):
+        self.f = np.load(path, mmap_mode="r")
+        self.length = int(self.f["dset_len"][0])
+
+    def get(self, i, mod):
+        return np.array(self.f[f"{i}_{mod}"])
+
+
+class _SyntheticFile:
+    def __init__(self, spec, geometry, num_target):
+        from .geometry import geometry_7b, geometry_mini
+        from .synthetic import synthetic_batch
+        self.seed, self.length = spec
+        self.g = geometry_mini(num_target=num_target) if geometry == "mini" else geometry_7b(num_target=num_target)
+        self._gen = synthetic_batch
+
+    def get(self, i, mod):
+        b = self._gen(self.g, 1, seed=self.seed * 100003 + i)
+        return b[mod][0].numpy()
+
+
+class VLB_Dataset(Dataset):
+    def __init__(self, ds_paths, geometry="7b", num_target=1000):
+        self.ds_files, self.length, self.ranges = {}, 0, []
+        for i, p in enumerate(ds_paths):
+            if isinstance(p, tuple):
+                f = _SyntheticFile(p, geometry, num_target)
+            elif str(p).endswith(".npz"):
+                f = _NpzFile(p)
+            else:
+                f = _H5File(p)
+            self.ds_files[i] = {"ds_file": f, "idx_from": self.length}
+            self.ranges.append((self.length, self.length + f.length))
+            self.length += f.length
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        i = get_idx(self.ranges, idx)
+        f = self.ds_files[i]["ds_file"]
+        k = idx - self.ds_files[i]["idx_from"]
+        item = {m: torch.from_numpy(np.asarray(f.get(k, m))).float() for m in MODS_T}
+        item.update({m: np.asarray(f.get(k, m)) for m in MODS_N})
+        return item
+
+
+@dataclass
+class VLBDatasets:
+    config: VLBDataModuleConfig
+    train: VLB_Dataset | None = None
+    val: VLB_Dataset | None = None
+    test: VLB_Dataset | None = None
+
+    def __post_init__(self):
+        c = self.config
+        if c.lazyload_path.startswith("synthetic:"):
+            n_files, n_samples = (int(x) for x in c.lazyload_path.split(":", 1)[1].split("x"))
+            f_list = [(c.random_state + k, n_samples) for k in range(n_files)]
+            names = [f"synthetic_{k}" for k in range(n_files)]
+        else:
+            f_list = []
+            for s in c.seasons:
+                f_list += sorted(glob.glob(
+                    c.lazyload_path.replace("$SCRATCH_PATH", os.environ.get("SCRATCH_PATH", ".")).replace("s*", f"{s}")))
+            names = [os.path.basename(x) for x in f_list]
+        if not f_list:
+            raise FileNotFoundError(f"no lazy-load files match {c.lazyload_path!r}")
+        r = np.random.RandomState(c.random_state)
+        vi = int(r.choice(len(f_list), 1)[0])
+        val_file = [f_list[vi]]
+        train_files = [x for x in f_list if x != f_list[vi]]
+        self.dset_names = {"val_set": [names[vi]], "train_set": [n for n, x in zip(names, f_list) if x != f_list[vi]]}
+        self.val = VLB_Dataset(val_file, c.geometry, c.num_target)
+        self.train = VLB_Dataset(train_files, c.geometry, c.num_target)
+
+
+class VLBDataModule(_Base):
+    def __init__(self, config: VLBDataModuleConfig) -> None:
+        super().__init__()
+        self.config = config
+        self.datasets = VLBDatasets(self.config)
+
+    def x_dataloader(self, dataset, shuffle: bool = True, sampler=None):
+        if dataset is None:
+            raise AttributeError
+        return DataLoader(dataset=dataset, batch_size=self.config.batch_size, shuffle=shuffle and sampler is None,
+                          sampler=sampler, num_workers=self.config.num_workers)
+
+    def train_dataloader(self, rank: int = 0, world: int = 1):
+        sampler = None
+        if world > 1:       # the reference has no DistributedSampler: ranks draw disjoint, rank-strided clips
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(self.datasets.train, num_replicas=world, rank=rank, shuffle=True,
+                                         seed=self.config.random_state, drop_last=True)
+        return self.x_dataloader(dataset=self.datasets.train, sampler=sampler)
+
+    def val_dataloader(self):
+        return self.x_dataloader(dataset=self.datasets.val, shuffle=self.config.shuffle_val_data)

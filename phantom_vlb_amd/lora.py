@@ -45,7 +45,7 @@ def lora_down(x, A, R, scale, p, seeds, out):
 
 def lora_dx_masked(u, At, dx, R, p, seeds):
     M, K = dx.shape
-    check(lib.vlb_lora_dx_masked(u.data_ptr(), u.stride(0), At.data_ptr(), dx.data_ptr(), dx.stride(0), M, K, R, p,
+    check(lib.vlb_lora_dx_masked(u.data_ptr(), u.stride(0), At.data_ptr(), At.stride(0), dx.data_ptr(), dx.stride(0), M, K, R, p,
                                  _seeds(seeds), _stream()), "vlb_lora_dx_masked")
 
 

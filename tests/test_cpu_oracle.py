@@ -170,3 +170,56 @@ def test_ops_refuse_cpu_tensors():
     import pytest
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_yaml_configs_load_like_the_reference():
+    """Same keys / values as config/experiment/*.yaml of the reference, resolved without Hydra."""
+    from phantom_vlb_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "config"), ["experiment=VLB_vllama2_friends_lora", "subject=sub-03"])
+    lm = cfg["litmodule"]["config"]
+    assert lm["_target_"].strip() == "src.litmodule.VLBLitModuleConfig"
+    assert (lm["use_lora"], lm["lora_r"], lm["lora_alpha"], lm["lora_dropout"]) == (True, 16, 32, 0.1)
+    assert lm["lr"] == 1e-4 and lm["eps"] == 1e-8 and lm["weight_decay"] == 1e-2 and lm["t_max"] == 50000
+    assert cfg["datamodule"]["config"]["batch_size"] == 3 and cfg["datamodule"]["config"]["subject"] == "sub-03"
+    assert cfg["trainer"]["precision"] == "bf16-mixed" and cfg["trainer"]["gradient_clip_val"] == 1
+    assert cfg["output_dir"].endswith("lora/sub-03") and cfg["random_state"] == 1234
+    assert cfg["_unresolved"] == ["my_api_key", "my_workspace"]          # config/logger is git-ignored upstream
+    base = load_config(os.path.join(ROOT, "config"), ["experiment=VLB_vllama2_friends_baseline", "subject=sub-01",
+                                                       "litmodule.config.num_target=2048"])
+    assert base["litmodule"]["config"]["freeze_backbone"] is True and base["litmodule"]["config"]["num_target"] == 2048
+    assert base["datamodule"]["config"]["batch_size"] == 5
+
+
+def test_datamodule_split_and_schema():
+    from src.datamodule import VLBDataModule, VLBDataModuleConfig
+    dm = VLBDataModule(VLBDataModuleConfig(lazyload_path="synthetic:4x3", subject="sub-01", seasons=["s1"], delay=3,
+                                           window=3, random_state=1234, shuffle_val_data=False, batch_size=2,
+                                           geometry="mini", num_target=128))
+    names = dm.datasets.dset_names
+    assert len(names["val_set"]) == 1 and len(names["train_set"]) == 3 and names["val_set"][0] not in names["train_set"]
+    assert len(dm.datasets.train) == 9 and len(dm.datasets.val) == 3
+    b = next(iter(dm.val_dataloader()))
+    assert set(b) == {"timeseries", "vision", "language", "padvals", "vis_weights", "lang_weights"}
+    assert b["vision"].dtype == torch.float32 and b["language"].dtype == torch.float32 and b["padvals"].dtype == torch.int64
+
+
+def test_streaming_pearson_callback_matches_definition():
+    from src import LogValAccuracyCallback
+
+    class M:
+        class config:
+            num_target = 5
+        logged = {}
+
+        def log(self, k, v):
+            self.logged[k] = float(v)
+    torch.manual_seed(0)
+    preds, vals = torch.randn(40, 5), torch.randn(40, 5)
+    vals[:, 0] = preds[:, 0] * 2 + 1
+    cb, m = LogValAccuracyCallback(), M()
+    cb.on_validation_epoch_start(None, m)
+    for i in range(0, 40, 8):
+        cb.on_validation_batch_end(None, m, {"brain_preds": preds[i:i + 8], "brain_vals": vals[i:i + 8]}, None, i)
+    cb.on_validation_epoch_end(None, m)
+    ref = torch.stack([torch.corrcoef(torch.stack([preds[:, j], vals[:, j]]))[0, 1] for j in range(5)])
+    assert torch.allclose(cb.correlations, ref, atol=1e-5) and abs(m.logged["val_corr_avg"] - float(ref.mean())) < 1e-5
