@@ -38,6 +38,8 @@ extern "C" {
 #define VLB_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): CLIP MLP (transformers modeling_clip.py CLIPMLP) */
 #define VLB_ACT_GELU 2       /* erf GELU: STC connector readout */
 #define VLB_ACT_SILU 3       /* SE fc1, sampler */
+#define VLB_ACT_SWIGLU_PAIR 4 /* MistralMLP act_fn(gate)*up fused into the gate/up GEMM: W rows interleaved in
+                                 16-row blocks [gate_b | up_b | gate_b+1 | ...]; C gets N/2 columns; no bias/residual */
 
 int vlb_abi_version(void);
 const char* vlb_last_error(void);
@@ -197,12 +199,14 @@ int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M
 /* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K, >=R] bf16 (transposed adapters, row stride ldat). */
 int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
                        const uint32_t* seeds_host, void* stream);
-/* Skinny weight gradient: dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep(X[m,k]) + beta * dW ; N <= 64.
- * dA = s*(dY B)^T drop(x)  (G = dY.B, X = x) and dB^T = (s*drop(x) A^T)^T dY  (G = t, X = dY, p = 0).
- * ws: fp32 [vlb_wgrad_splits(M), N, K] partial slabs (fixed-order sum: reproducible). */
+/* Skinny weight gradient (MFMA, both operands read transposed from LDS):
+ *   dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep_g(X[m,k]) + beta * dW ;  N in {16,32,48}, g = n/16.
+ * dA of all projections sharing x in one launch (G = [u_q|u_k|u_v], X = x, one dropout seed per
+ * 16-rank group) and dB^T = t^T dY (G = t, X = dY, p = 0).  ws: fp32 [vlb_wgrad_splits(M), N, K]
+ * partial slabs summed in a fixed order (reproducible).  seeds_host: N/16 host uint32, NULL if p == 0. */
 int vlb_wgrad_splits(int M);
 int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
-                     float alpha, float beta, float drop_p, uint32_t drop_seed, void* stream);
+                     float alpha, float beta, float drop_p, const uint32_t* seeds_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (litmodule :345-379 AdamW + CosineAnnealingLR; Trainer gradient_clip_val).

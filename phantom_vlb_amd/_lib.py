@@ -9,6 +9,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
+# torch FIRST: its wheel bundles its own libamdhip64; libvlb.so must bind to that already-loaded HIP
+# runtime (same SONAME) instead of pulling a second copy from /opt/rocm, or the two runtimes fight
+# over the device ("no ROCm-capable device is detected" on the first libvlb launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlb.so")
 
@@ -44,7 +49,7 @@ SIGNATURES = {
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P],
     "vlb_wgrad_splits": [I],
-    "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, ctypes.c_uint32, P],
+    "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
     "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],
     "vlb_lora_dx_masked": [P, I, P, I, P, I, I, I, I, F, P, P],
     "vlb_grad_sumsq": [P, L, P, P],

@@ -94,8 +94,12 @@ class Weights:
                 wqkv=_bf(torch.cat([sd[f"{p}.self_attn.q_proj.weight"], sd[f"{p}.self_attn.k_proj.weight"],
                                     sd[f"{p}.self_attn.v_proj.weight"]], 0), d),
                 wo=_bf(sd[f"{p}.self_attn.o_proj.weight"], d),
-                wgu=_bf(torch.cat([sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"]], 0), d),
                 wdown=_bf(sd[f"{p}.mlp.down_proj.weight"], d))
+            if keep_transposed:    # LoRA: backward needs the gate/up pre-activations, keep them separate
+                lw["wgu"] = _bf(torch.cat([sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"]], 0), d)
+            else:                  # frozen: SwiGLU is fused into the GEMM epilogue (interleaved rows)
+                lw["wgu_il"] = ops.interleave_gate_up(_bf(sd[f"{p}.mlp.gate_proj.weight"], d),
+                                                      _bf(sd[f"{p}.mlp.up_proj.weight"], d))
             if keep_transposed:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     lw[k + "_t"] = ops.transpose(lw[k])
@@ -251,8 +255,10 @@ class Backbone:
                               True, g.head_dim ** -0.5, key_mask=key_mask)
         x = ops.gemm(a, lw["wo"], residual=x)
         h = ops.rmsnorm(x, lw["post_norm"], g.rms_eps)
-        gu = ops.gemm(h, lw["wgu"])
-        h = ops.swiglu(gu)
+        if lw.get("wgu_il") is not None:
+            h = ops.gemm(h, lw["wgu_il"], act=ops.ACT_SWIGLU_PAIR)
+        else:
+            h = ops.swiglu(ops.gemm(h, lw["wgu"]))
         return ops.gemm(h, lw["wdown"], residual=x)
 
     def splice(self, ids, video_tokens):
@@ -260,21 +266,20 @@ class Backbone:
         return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag)
 
     # ---------------- fsdp.yaml-equivalent sharding of the frozen decoder weights (opt-in)
-    SHARD_KEYS = ("wqkv", "wo", "wgu", "wdown")
-
     def enable_sharding(self, group=None):
         """Keep only this rank's 1/world shard of every decoder layer; full layers are all-gathered one
         layer ahead of compute on a side stream (parallel.ShardedLayerStore)."""
         from .parallel import ShardedLayerStore
         side = torch.cuda.Stream(device=self.w.dev)
-        self.store = ShardedLayerStore(self.w.layers, self.SHARD_KEYS, group, stream=side)
+        keys = tuple(k for k in ("wqkv", "wo", "wgu", "wgu_il", "wdown") if k in self.w.layers[0])
+        self.store = ShardedLayerStore(self.w.layers, keys, group, stream=side)
         self.store_t = None
         if "wqkv_t" in self.w.layers[0]:
-            tkeys = tuple(k + "_t" for k in self.SHARD_KEYS)
+            tkeys = tuple(k + "_t" for k in keys)
             self.store_t = ShardedLayerStore(self.w.layers, tkeys, group, stream=side)
         for lw in self.w.layers:
             for k in list(lw):
-                if k in self.SHARD_KEYS or k.endswith("_t"):
+                if k in keys or k.endswith("_t"):
                     lw[k] = None
         torch.cuda.empty_cache()
 

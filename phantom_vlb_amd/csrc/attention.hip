@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   constexpr int D = 128, ROWB = 256;
-  constexpr int K_OFF = 0, V_OFF = BK_KEYS * ROWB;                 // 32 KB each
-  constexpr int QT_OFF = 2 * BK_KEYS * ROWB;                       // [2][Q tile 8 KB | dO tile 8 KB]
+  constexpr int K_OFF = 0;                                         // K tile 32 KB (V lives in registers)
+  constexpr int QT_OFF = BK_KEYS * ROWB;                           // [2][Q tile 8 KB | dO tile 8 KB]
   constexpr int QT_BYTES = BQ * ROWB;
   constexpr int T_OFF = QT_OFF + 4 * QT_BYTES;                     // dS^T image [128 keys][32 q] bf16 = 8 KB
   constexpr int L_OFF = T_OFF + BK_KEYS * 64;                      // [2][lse 32 f32 | delta 32 f32]
@@ -329,13 +329,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
 
   const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
   const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
-  // ---- stage K and V once (8 pieces of 4 rows per wave each)
+  // ---- stage K once into LDS (8 pieces of 4 rows per wave); V fragments go straight to registers:
+  // lane (key = wave*32 + ql, h) holds V[key][16ks + 8h .. +8], the B operand of dP = dO.V^T
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int piece = 4 * i + wave, r = piece * 4 + sr;
     const int key = min(k0 + r, p.S - 1);
     glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, smem + K_OFF + piece * 1024);
-    glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
+  }
+  bf16x8 vreg[8];
+  {
+    const int vkey = min(k0 + wave * 32 + ql, p.S - 1);
+    const bf16* vp = vbase + (int64_t)vkey * p.ldv + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) vreg[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
   }
   const int nqb = (p.S + BQ - 1) / BQ;
   const int qb0 = CAUSAL ? (k0 / BQ) : 0;
@@ -424,8 +431,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + K_OFF + kv_rd[ks]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);
       const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_rd[ks]);
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + kv_rd[ks]);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vreg[ks], pacc, 0, 0, 0);
+      if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // bound the live range of hoisted fragment loads
     }
     // ---- P = exp(S*scale - lse), dS = scale * P * (dP - delta); rows q = (r&3) + 8(r>>2) + 4h
     bf16x8 pb[2], dsb[2];
@@ -546,7 +553,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask,
                 (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
-  constexpr int LDS = 2 * BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
+  constexpr int LDS = BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
   static bool configured = false;
   if (!configured) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

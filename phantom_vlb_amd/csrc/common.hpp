@@ -40,7 +40,12 @@ void vlb_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
-static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream argument right before launching: clear any stale (sticky)
+// error another HIP user of this thread left behind, so VLB_LAUNCH_CHECK reports only our own launch.
+static inline hipStream_t as_stream(void* s) {
+  (void)hipGetLastError();
+  return reinterpret_cast<hipStream_t>(s);
+}
 
 // ---- device helpers ----
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

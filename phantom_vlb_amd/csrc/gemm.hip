@@ -205,7 +205,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
 // with ONE vmcnt(0) per tile placed just before the barrier that precedes the first read of tile t+1,
 // i.e. after ~3-4 intervals of flight.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// S0..S3: how many of the tile's LDS-DMA instructions a wave issues in load slot 0..3 of the 4-interval
+// window that precedes the tile's first read (slot q of group 0 = its segments L0,C0,L1,C1 of tile t;
+// of group 1 = C1 of tile t-1, then L0,C0,L1 of tile t).  S0+S1+S2+S3 = A_LD + B_LD.
+template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   static_assert(WM * WN == 8 && WM % 2 == 0, "8 waves, groups split along M");
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -256,22 +259,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   const int nk1 = p.K / BK;
   const int nk = nk1 + p.K2 / BK;
 
-  auto stage = [&](int buf, int kt) {
+  static_assert(S0 + S1 + S2 + S3 == A_LD + B_LD, "slot counts must cover the tile");
+  // instruction index i of a tile: 0..A_LD-1 = A pieces, A_LD.. = W pieces
+  auto stage_range = [&](int buf, int kt, int from, int to) {
     char* base = smem + buf * STAGE + wave * 8 * ROW_BYTES;
-    if (kt < nk1) {
-      const int ko = kt * BK;
+    const bool first = kt < nk1;
+    const int ko = (first ? kt : kt - nk1) * BK;
 #pragma unroll
-      for (int i = 0; i < A_LD; ++i) glds16(a_src[i] + ko, base + i * 64 * ROW_BYTES);
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) glds16(b_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
-    } else {
-      const int ko = (kt - nk1) * BK;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) glds16(a2_src[i] + ko, base + i * 64 * ROW_BYTES);
-#pragma unroll
-      for (int i = 0; i < B_LD; ++i) glds16(b2_src[i] + ko, base + A_BYTES + i * 64 * ROW_BYTES);
+    for (int i = 0; i < A_LD + B_LD; ++i) {
+      if (i < from || i >= to) continue;
+      if (i < A_LD) glds16((first ? a_src[i] : a2_src[i]) + ko, base + i * 64 * ROW_BYTES);
+      else glds16((first ? b_src[i - A_LD] : b2_src[i - A_LD]) + ko, base + A_BYTES + (i - A_LD) * 64 * ROW_BYTES);
     }
   };
+  auto stage = [&](int buf, int kt) { stage_range(buf, kt, 0, A_LD + B_LD); };
+  constexpr int O1 = S0, O2 = S0 + S1, O3 = S0 + S1 + S2, O4 = A_LD + B_LD;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -308,6 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   bf16x8 af[MT], wf[NT];
   for (int kt = 0; kt < nk; ++kt) {
     const char* sb = smem + (kt & 1) * STAGE;
+    const int nb = (kt & 1) ^ 1;                       // buffer of tile kt+1 (and of tile kt+2: kt&1)
+    const bool ld1 = kt >= 1 && kt + 1 < nk;           // this window loads tile kt+1
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // ---------------- LOAD segment
@@ -315,7 +319,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
       for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks]);
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i][ks]);
-      if (ks == 0 && kt >= 1 && kt + 1 < nk) stage((kt & 1) ^ 1, kt + 1);
+      if (ld1) {
+        if (grp == 0) { if (ks == 0) stage_range(nb, kt + 1, 0, O1); else stage_range(nb, kt + 1, O2, O3); }
+        else          { if (ks == 0) stage_range(nb, kt + 1, O1, O2); else stage_range(nb, kt + 1, O3, O4); }
+      }
       PP_LGKM0();
       if (ks == 1 && grp == 1 && kt >= 1) PP_VM0();
       PP_BARRIER();
@@ -327,6 +334,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) {
+        if (ld1) { if (ks == 0) stage_range(nb, kt + 1, O1, O2); else stage_range(nb, kt + 1, O3, O4); }
+      } else {
+        if (ks == 0) { if (ld1) stage_range(nb, kt + 1, O2, O3); }
+        else if (kt + 2 < nk) stage_range(kt & 1, kt + 2, 0, O1);   // slot 0 of the NEXT window
+      }
       if (ks == 1 && grp == 0 && kt >= 1) PP_VM0();
       PP_BARRIER();
     }
@@ -336,6 +349,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
 #undef PP_LGKM0
 #undef PP_VM0
 
+  if (p.act == VLB_ACT_SWIGLU_PAIR) {
+    // W rows are interleaved in 16-row blocks [gate_b | up_b]: n-tiles (2j, 2j+1) hold gate and up of the
+    // same 16 output features at the same lane/register positions -> out = silu(gate) * up, N/2 columns.
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * TM + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(acc[i][j][e]) * acc[i][j + 1][e]);
+        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * TM + i * 16 + fr;
@@ -415,6 +446,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
+  if (p.act == VLB_ACT_SWIGLU_PAIR) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 32 + i * 16 + fr;
+      if (m >= p.M) continue;
+      const int nb = (n0 + wn * 32) / 2 + fq * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (2 * (nb + e) < p.N) p.C[(int64_t)m * p.ldc + nb + e] = (bf16)(silu_f(acc[i][0][e]) * acc[i][1][e]);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 32 + i * 16 + fr;
@@ -439,6 +482,23 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 int g_variant = 1;      // 0: lock-step double buffer, 1: ping-pong wave groups (default)
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 
+template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3>
+int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+      return VLB_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_tile(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
@@ -454,20 +514,17 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
   }
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = a.N / BN;
-  if (g_variant == 1) {
-    static bool configured_pp = false;
-    if (!configured_pp) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) {
-        vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-        return VLB_ERR_LAUNCH;
-      }
-      configured_pp = true;
-    }
-    hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
-    VLB_LAUNCH_CHECK();
-    return VLB_OK;
+  if (g_variant == 1 || (g_variant == 0 && a.act == VLB_ACT_SWIGLU_PAIR)) {
+    return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+  }
+  constexpr int T = (BM + BN) / 64;     // LDS-DMA instructions per thread per K-tile
+  if (g_variant == 2) return launch_pp<BM, BN, WM, WN, T / 2, 0, T - T / 2, 0>(a, s, LDS);
+  if (g_variant == 3) return launch_pp<BM, BN, WM, WN, T / 4, T / 4, T / 4, T - 3 * (T / 4)>(a, s, LDS);
+  if (g_variant == 4) return launch_pp<BM, BN, WM, WN, 0, T / 2, 0, T - T / 2>(a, s, LDS);
+  if (g_variant == 5) return launch_pp<BM, BN, WM, WN, 3 * T / 8, T / 8, 3 * T / 8, T - 3 * T / 8 - T / 8 - 3 * T / 8>(a, s, LDS);
+  if (g_variant != 0) {
+    vlb_set_error("gemm: unknown kernel variant %d", g_variant);
+    return VLB_ERR_INVALID;
   }
   hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
   VLB_LAUNCH_CHECK();
@@ -512,7 +569,7 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   VLB_REQUIRE(A && W && C, "gemm: null operand");
   VLB_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VLB_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
-  VLB_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than row");
+  VLB_REQUIRE(lda >= K && ldw >= K && (ldc >= N || (act == VLB_ACT_SWIGLU_PAIR && ldc >= N / 2)), "gemm: leading dimension smaller than row");
   if (K2 > 0) {
     VLB_REQUIRE(A2 && W2, "gemm: K2>0 needs A2 and W2");
     VLB_REQUIRE(K2 % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && lda2 >= K2 && ldw2 >= K2, "gemm: bad second operand pair");
@@ -520,6 +577,9 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
     A2 = nullptr; W2 = nullptr; K2 = 0;
   }
   if (residual) VLB_REQUIRE(ldr >= N, "gemm: ldr < N");
+  if (act == VLB_ACT_SWIGLU_PAIR) {
+    VLB_REQUIRE(N % 32 == 0 && !bias && !residual && ldc >= N / 2, "gemm: SWIGLU_PAIR needs N %% 32 == 0, no bias/residual, ldc >= N/2");
+  }
   GemmArgs a;
   a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = (bf16*)C;
   a.A2 = (const bf16*)A2; a.W2 = (const bf16*)W2;

@@ -34,21 +34,25 @@ __device__ __forceinline__ void keep8(uint32_t seed, int64_t m, int K, int k0, u
 struct Seeds { uint32_t s[8]; };
 
 // ---------------------------------------------------------------- t = scale * drop(x) . A^T
-// one wave = 16 rows of x; MFMA rows = adapter ranks, MFMA cols = rows of x.
+// one block = 16 rows of x; its 4 waves each take a quarter of K (4 independent loads in flight per
+// wave) and the partial 16x16 tiles are summed through LDS.  MFMA rows = adapter ranks, cols = rows of x.
 template <int G>   // number of 16-rank groups (projections sharing this x)
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ A,
                                                         bf16* __restrict__ t, int ldt, int M, int K, float scale,
                                                         uint32_t thresh, Seeds seeds) {
+  __shared__ float red[3][G][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = (blockIdx.x * 4 + wave) * 16;
-  if (m0 >= M) return;
+  const int m0 = blockIdx.x * 16;
   const int fr = lane & 15, fq = lane >> 4;
   const int m = min(m0 + fr, M - 1);
   f32x4 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16* xr = x + (int64_t)m * ldx + fq * 8;
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  const int kq = ((K / 32 + 3) / 4) * 32;            // K range of this wave, a multiple of 32
+  const int kbeg = wave * kq, kend = min(K, kbeg + kq);
+#pragma unroll 4
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + k0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -63,12 +67,20 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16* __restrict__
       acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm, acc[g], 0, 0, 0);
     }
   }
-  if (m0 + fr < M) {
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave - 1][g][e][lane] = acc[g][e];
+  }
+  __syncthreads();
+  if (wave == 0 && m0 + fr < M) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[g][e] * scale);
+      for (int e = 0; e < 4; ++e)
+        o[e] = (bf16)((acc[g][e] + red[0][g][e][lane] + red[1][g][e][lane] + red[2][g][e][lane]) * scale);
       *reinterpret_cast<bf16x4*>(t + (int64_t)(m0 + fr) * ldt + 16 * g + fq * 4) = o;
     }
   }
@@ -126,75 +138,123 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
   }
 }
 
-// ---------------------------------------------------------------- skinny wgrad
-constexpr int WG_N = 16;        // output rows per pass
-constexpr int WG_ROWS = 128;    // rows of M per split (minimum)
+// ---------------------------------------------------------------- skinny wgrad (MFMA)
+// dW[16G, K] partials: contraction over the ROWS m of G[m, 16G] and X[m, K].  Both MFMA operands are
+// therefore "k-strided": the X tile [32 rows][256 cols] and the G tile [32 rows][16G] are staged
+// row-major in LDS (X by LDS-DMA, swizzled on the source) and read with ds_read_b64_tr_b16.
+// Block = 4 waves, 256 columns of K; wave = 64 columns (4 MFMA column tiles) x 16G ranks.
+// grid (ceil(K/256), splits); ws[split][16G][K] fp32 partial slabs, summed in a fixed order afterwards.
+constexpr int WG_COLS = 256;
+constexpr int WG_STEP = 32;     // rows of M per MFMA k-step
 
-// grid (ceil(K/512), splits), block 256.  ws[split][N][K] partial slabs.
-__global__ __launch_bounds__(256) void wgrad_partial_kernel(const bf16* __restrict__ G, int ldg, const bf16* __restrict__ X,
-                                                            int ldx, float* __restrict__ ws, int M, int N, int K, int n0,
-                                                            int rows_per_split, uint32_t thresh, uint32_t seed) {
-  __shared__ float red[WG_N][512];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 512 + lane * 8;
-  const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
-  const int nn = min(WG_N, N - n0);
-  float acc[WG_N][8];
-#pragma unroll
-  for (int i = 0; i < WG_N; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-  if (c < K) {
-    for (int m = r0 + wave; m < r1; m += 4) {
-      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + c);
-      float xf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = (float)xv[j];
-      if (thresh != 0) {
-        bool keep[8];
-        keep8(seed, m, K, c, thresh, keep);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[j] = keep[j] ? xf[j] : 0.f;
-      }
-      const bf16* gr = G + (int64_t)m * ldg + n0;
-#pragma unroll
-      for (int i = 0; i < WG_N; ++i) {
-        if (i < nn) {
-          const float gv = (float)gr[i];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][j] += gv * xf[j];
-        }
-      }
-    }
-  }
-  // sum the 4 waves in a fixed order
-  for (int w = 1; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-#pragma unroll
-      for (int i = 0; i < WG_N; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[i][lane * 8 + j] = acc[i][j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < WG_N; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] += red[i][lane * 8 + j];
-    }
-  }
-  if (wave == 0 && c < K) {
-#pragma unroll
-    for (int i = 0; i < WG_N; ++i) {
-      if (i < nn) {
-        float* o = ws + ((int64_t)blockIdx.y * N + n0 + i) * K + c;
-        *reinterpret_cast<f32x4*>(o) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-        *reinterpret_cast<f32x4*>(o + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
-      }
-    }
-  }
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16_l(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                   (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
+// 32-byte pair slot swizzle of the X tile: rows r and r+8 and the 4 rows of a transposed read all differ
+__device__ __forceinline__ int xsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict__ Gm, int ldg, const bf16* __restrict__ X,
+                                                         int ldx, float* __restrict__ ws, int M, int K,
+                                                         int rows_per_split, uint32_t thresh, Seeds seeds) {
+  constexpr int XT = WG_STEP * WG_COLS * 2;          // 16 KB
+  constexpr int GT = WG_STEP * 16 * G * 2;           // 1 KB per group
+  __shared__ __attribute__((aligned(16))) char smem[2 * (XT + GT)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * WG_COLS;
+  const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  const int N = 16 * G;
+
+  f32x4 acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: X piece i of this wave = rows 2*(4i+wave) + (lane>>5); 16-byte position pc = lane & 31
+  auto stage = [&](int buf, int m0) {
+    char* xb = smem + buf * (XT + GT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = 4 * i + wave, r = 2 * piece + (lane >> 5), pc = lane & 31;
+      const int chunk = (((pc >> 1) ^ xsw(r)) << 1) | (pc & 1);
+      const int m = min(m0 + r, M - 1);                        // rows past the end are zeroed through G
+      const int col = min(c0 + chunk * 8, K - 8);
+      glds16_l(X + (int64_t)m * ldx + col, xb + piece * 1024);
+    }
+    // G tile: 32 rows x 16G columns, 16-byte chunks; zero rows beyond the split so they contribute nothing
+    for (int i = tid; i < WG_STEP * 2 * G; i += 256) {
+      const int r = i / (2 * G), ch = i % (2 * G);
+      bf16x8 v = bf16x8{};
+      if (m0 + r < r1) v = *reinterpret_cast<const bf16x8*>(Gm + (int64_t)(m0 + r) * ldg + ch * 8);
+      *reinterpret_cast<bf16x8*>(xb + XT + r * 32 * G + ch * 16) = v;
+    }
+  };
+
+  const int nsteps = (r1 - r0 + WG_STEP - 1) / WG_STEP;
+  if (nsteps > 0) stage(0, r0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1, m0 = r0 + st * WG_STEP;
+    if (st + 1 < nsteps) stage(cur ^ 1, m0 + WG_STEP);
+    const char* xb = smem + cur * (XT + GT);
+    const char* gb = xb + XT;
+    // A' fragments (G^T): rows 8fq + {0..3} and + 4, columns 16g + 4tp
+    bf16x8 af[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(gb + (8 * fq + tq) * 32 * G + (16 * g + 4 * tp) * 2));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(gb + (8 * fq + 4 + tq) * 32 * G + (16 * g + 4 * tp) * 2));
+      af[g] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int colb = wave * 64 + n * 16;                  // column block inside the tile
+      // B' fragment (X): lane fr gets column colb+fr of rows 8fq + {0..7}
+      const int ra = 8 * fq + tq, rb = ra + 4;
+      const int pa = (((colb >> 4) ^ xsw(ra)) << 5) + ((4 * tp) << 1);
+      const int pb = (((colb >> 4) ^ xsw(rb)) << 5) + ((4 * tp) << 1);
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + ra * 512 + pa));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + rb * 512 + pb));
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      const int col = c0 + colb + fr;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bf16x8 xm = xf;
+        if (thresh != 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t hsh = drop_bits_pair(seeds.s[g], m0 + 8 * fq + j, K, col >> 1);
+            const uint32_t bits = (col & 1) ? (hsh >> 16) : (hsh & 0xffffu);
+            if (bits < thresh) xm[j] = (bf16)0.f;
+          }
+        }
+        acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], xm, acc[g][n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // partial slab: lane owns column c0 + wave*64 + n*16 + fr of ranks 16g + 4fq + {0..3}
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int col = c0 + wave * 64 + n * 16 + fr;
+      if (col < K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ws[((int64_t)blockIdx.y * N + 16 * g + 4 * fq + e) * K + col] = acc[g][n][e];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int splits, int64_t nk, float alpha,
                                     float beta) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
@@ -212,24 +272,31 @@ inline uint32_t thresh16(float p) {
 }  // namespace
 
 extern "C" int vlb_wgrad_splits(int M) {
-  int s = (M + WG_ROWS - 1) / WG_ROWS;
+  int s = (M + 255) / 256;                 // >= 256 rows (8 MFMA k-steps) per split
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
 extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
-                                float alpha, float beta, float drop_p, uint32_t drop_seed, void* stream) {
+                                float alpha, float beta, float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(G && X && dW && ws, "wgrad_skinny: null operand");
-  VLB_REQUIRE(M > 0 && N > 0 && N <= 64 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "wgrad_skinny: bad shape M=%d N=%d K=%d", M, N, K);
-  VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "wgrad_skinny: bad dropout p");
+  VLB_REQUIRE(M > 0 && (N == 16 || N == 32 || N == 48) && K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ldg % 8 == 0,
+              "wgrad_skinny: bad shape M=%d N=%d K=%d (N must be 16, 32 or 48)", M, N, K);
+  VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "wgrad_skinny: bad dropout arguments");
+  VLB_REQUIRE((((uintptr_t)G | (uintptr_t)X) % 16) == 0, "wgrad_skinny: operands must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
   const int splits = vlb_wgrad_splits(M);
-  const int rps = (M + splits - 1) / splits;
+  const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
   const float inv_keep = 1.f / (1.f - drop_p);
-  for (int n0 = 0; n0 < N; n0 += WG_N) {
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((K + 511) / 512, splits), dim3(256), 0, st, (const bf16*)G, ldg,
-                       (const bf16*)X, ldx, ws, M, N, K, n0, rps, thresh16(drop_p), drop_seed);
-    VLB_LAUNCH_CHECK();
+  Seeds sd{};
+  for (int g = 0; g < N / 16; ++g) sd.s[g] = seeds_host ? seeds_host[g] : 0u;
+  dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
+  const uint32_t th = thresh16(drop_p);
+  switch (N / 16) {
+    case 1: hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
+    case 2: hipLaunchKernelGGL(wgrad_mfma_kernel<2>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
+    default: hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
   }
+  VLB_LAUNCH_CHECK();
   const int64_t nk = (int64_t)N * K;
   int blocks = (int)((nk + 255) / 256); if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dW, splits, nk, alpha * inv_keep, beta);
@@ -246,7 +313,7 @@ extern "C" int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int
   Seeds s{};
   for (int g = 0; g < R / 16; ++g) s.s[g] = seeds_host ? seeds_host[g] : 0u;
   const float sc = scale / (1.f - drop_p);
-  dim3 grid((M + 63) / 64);
+  dim3 grid((M + 15) / 16);
   hipStream_t st = as_stream(stream);
   const uint32_t th = thresh16(drop_p);
   switch (R / 16) {

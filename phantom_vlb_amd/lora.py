@@ -49,10 +49,11 @@ def lora_dx_masked(u, At, dx, R, p, seeds):
                                  _seeds(seeds), _stream()), "vlb_lora_dx_masked")
 
 
-def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seed=0):
+def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seeds=None):
+    """dW [N,K] fp32 (contiguous) = alpha/(1-p) * G[:, :N]^T keep(X) + beta*dW; N in {16,32,48}."""
     M, K = X.shape
     check(lib.vlb_wgrad_skinny(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), ws.data_ptr(), M, N, K,
-                               alpha, beta, p, seed & 0xFFFFFFFF, _stream()), "vlb_wgrad_skinny")
+                               alpha, beta, p, _seeds(seeds) if p > 0 else None, _stream()), "vlb_wgrad_skinny")
 
 
 # (group name, [(target, out rows attr)], input) - projections in one group share their input
@@ -103,7 +104,18 @@ class LoraState:
                     self.master[f"{pre}.lora_A.weight"] = a0.to(device).contiguous()
                     self.master[f"{pre}.lora_B.weight"] = b0.to(device).contiguous()    # stored as B^T [r,out]
             self.layers.append(lay)
-        self.grads = {n: torch.zeros_like(t) for n, t in self.master.items()}
+        # gradients: A-grads of a group are row-slices of one stacked [R,in] buffer (one wgrad launch per group)
+        self.grads = {}
+        self.grad_A = []
+        for i in range(g.layers):
+            ga = {}
+            for gname, targets in GROUPS:
+                buf = torch.zeros(16 * len(targets), self.in_dims[targets[0]], dtype=torch.float32, device=device)
+                ga[gname] = buf
+                for j, t in enumerate(targets):
+                    self.grads[f"model.layers.{i}.{t}.lora_A.weight"] = buf[16 * j:16 * j + 16]
+                    self.grads[f"model.layers.{i}.{t}.lora_B.weight"] = torch.zeros(16, self.out_dims[t], dtype=torch.float32, device=device)
+            self.grad_A.append(ga)
         # bf16 compute copies the optimiser refreshes in place: A rows inside the stacked matrix, B^T separate
         self.bt = {n: torch.zeros(t.shape, dtype=BF16, device=device) for n, t in self.master.items() if "lora_B" in n}
         self.refresh(from_master=True)
@@ -152,7 +164,7 @@ class LoraState:
         if self._ws is None or self._ws["M"] != M:
             g, d = self.g, self.dev
             kmax = max(g.ff, g.dim, g.heads * g.head_dim)
-            self._ws = dict(M=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 16 * kmax, dtype=torch.float32, device=d),
+            self._ws = dict(M=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
                             u=torch.zeros(M, PAD, dtype=BF16, device=d))
         return self._ws
 
@@ -207,10 +219,9 @@ class LoraState:
             lora_down(dyj, self.bt[f"{pre}.lora_B.weight"], 16, self.scale, 0.0, None, u[:, 16 * j:16 * j + 16])
             # dB^T[r,out] = sum_m t[m,r] dy[m,out]      (t carries s and 1/(1-p))
             wgrad_skinny(t[:, 16 * j:16 * j + 16], dyj, self.grads[f"{pre}.lora_B.weight"], ws["wg"], 16)
-            # dA[r,in] = sum_m u[m,r] keep(x[m,in])/(1-p)
-            wgrad_skinny(u[:, 16 * j:16 * j + 16], x_in, self.grads[f"{pre}.lora_A.weight"], ws["wg"], 16, p=self.p,
-                         seed=seeds[j])
             col += n
+        # dA[r,in] = sum_m u[m,r] keep_g(x[m,in])/(1-p) for every projection of the group in one pass over x
+        wgrad_skinny(u, x_in, self.grad_A[li][gname], ws["wg"], lay["R"], p=self.p, seeds=seeds)
         if not need_dx:
             return None
         if self.p == 0.0:

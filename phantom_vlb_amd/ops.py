@@ -9,7 +9,7 @@ import torch
 
 from ._lib import check, lib
 
-ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SILU, ACT_SWIGLU_PAIR = 0, 1, 2, 3, 4
 BF16 = torch.bfloat16
 
 
@@ -63,7 +63,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
     if out is None:
-        out = torch.empty(M, N, dtype=BF16, device=a.device)
+        out = torch.empty(M, N // 2 if act == ACT_SWIGLU_PAIR else N, dtype=BF16, device=a.device)
     K2 = 0
     if a2 is not None:
         K2 = a2.shape[1]
@@ -81,6 +81,13 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     if timed:
         e1.record()
     return out
+
+
+def interleave_gate_up(w_gate, w_up):
+    """[gate; up] -> 16-row blocks [gate_0 | up_0 | gate_1 | up_1 | ...] for ACT_SWIGLU_PAIR."""
+    ff, k = w_gate.shape
+    assert ff % 16 == 0
+    return torch.stack([w_gate.view(ff // 16, 16, k), w_up.view(ff // 16, 16, k)], 1).reshape(2 * ff, k).contiguous()
 
 
 def transpose(x):

@@ -65,6 +65,21 @@ def test_gemm_second_operand_pair(dev, M, N, K, K2):
     assert rel_err(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("M,ff,K", [(512, 256, 128), (300, 128, 64), (40, 48, 64)])
+def test_gemm_swiglu_pair_epilogue(dev, M, ff, K):
+    """gate/up GEMM with MistralMLP's act_fn(gate)*up fused (interleaved weight rows), tile + generic kernels."""
+    from phantom_vlb_amd import ops
+    a = _r(M, K, dev=dev)
+    wg, wu = _r(ff, K, dev=dev, scale=0.1, seed=1), _r(ff, K, dev=dev, scale=0.1, seed=2)
+    out = ops.gemm(a, ops.interleave_gate_up(wg, wu), act=ops.ACT_SWIGLU_PAIR)
+    assert out.shape == (M, ff)
+    ref = F.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert rel_err(out, ref) < 8e-3
+    # identical to the unfused pair of kernels up to one bf16 rounding of the pre-activations
+    unfused = ops.swiglu(ops.gemm(a, torch.cat([wg, wu], 0)))
+    assert rel_err(out, unfused.float()) < 1.5e-2
+
+
 def test_gemm_strided_views_and_alias(dev):
     from phantom_vlb_amd import ops
     M, N, K = 512, 256, 128

@@ -101,22 +101,26 @@ def test_lora_dx_masked(dev, G, p):
     assert rel_err(dx, ref) < 1e-2
 
 
-@pytest.mark.parametrize("M,N,K,p", [(300, 16, 512, 0.0), (1000, 16, 1024, 0.1), (64, 16, 4096, 0.0)])
+@pytest.mark.parametrize("M,N,K,p", [(300, 16, 512, 0.0), (1000, 16, 1024, 0.1), (64, 48, 4096, 0.0), (700, 32, 776, 0.1),
+                                     (2048, 48, 1024, 0.1)])
 def test_wgrad_skinny(dev, M, N, K, p):
     from phantom_vlb_amd._lib import lib
     from phantom_vlb_amd.lora import wgrad_skinny
     Gm = torch.zeros(M, 64, dtype=BF, device=dev)
-    Gm[:, 16:32] = _r(M, N, dev=dev)
+    Gm[:, :N] = _r(M, N, dev=dev)
     X = _r(M, K + 64, dev=dev, seed=2)[:, :K]                 # strided view
     dW = torch.full((N, K), 7.0, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.vlb_wgrad_splits(M) * N * K, dtype=torch.float32, device=dev)
-    wgrad_skinny(Gm[:, 16:32], X, dW, ws, N, alpha=0.5, beta=0.0, p=p, seed=99)
-    xm = X.float().cpu()
-    if p > 0:
-        xm = xm * keep_mask(99, M, K, p) / (1 - p)
-    ref = 0.5 * Gm[:, 16:32].float().cpu().t() @ xm
+    seeds = [99 + 5 * g for g in range(N // 16)]
+    wgrad_skinny(Gm, X, dW, ws, N, alpha=0.5, beta=0.0, p=p, seeds=seeds)
+    ref = torch.zeros(N, K)
+    for g in range(N // 16):
+        xm = X.float().cpu()
+        if p > 0:
+            xm = xm * keep_mask(seeds[g], M, K, p) / (1 - p)
+        ref[16 * g:16 * g + 16] = 0.5 * Gm[:, 16 * g:16 * g + 16].float().cpu().t() @ xm
     assert rel_err(dW, ref) < 2e-3
-    wgrad_skinny(Gm[:, 16:32], X, dW, ws, N, alpha=0.5, beta=1.0, p=p, seed=99)     # accumulate
+    wgrad_skinny(Gm, X, dW, ws, N, alpha=0.5, beta=1.0, p=p, seeds=seeds)     # accumulate
     assert rel_err(dW, 2 * ref) < 2e-3
 
 
