@@ -23,6 +23,25 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// ds_read_b64_tr_b16 through inline asm.  hipcc treats the builtin as possibly aliasing a pending LDS-DMA
+// and drains vmcnt(0) in front of it (which here also waits for the fp32 dQ atomics); the asm form is
+// invisible to that bookkeeping, so every batch of reads below is followed by an explicit lgkmcnt(0)
+// and a sched_barrier before its first consumer (cdna_hip_programming.md 5.7, form iii).
+__device__ __forceinline__ s16x4 tr_read_asm(const char* lds_ptr) {
+  s16x4 v;
+  const unsigned a = (unsigned)(uintptr_t)(const char __attribute__((address_space(3)))*)lds_ptr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
+__device__ __forceinline__ void lds_wait_all() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 struct AttnArgs {
   const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
   const uint8_t* mask;
@@ -135,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
           st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[s], 0, 0, 0);
         }
       }
-      // ---- masks: key validity (padding + sequence end) as one 64-bit word, causal on diagonal tiles
+      // ---- masks: key validity (padding + sequence end) as one 64-bit word, causal on diagonal tiles.
+      // The masked path is a separate wave-uniform branch (most tiles are full and skip it entirely).
       unsigned long long kvalid;
       {
         const int key = key0 + lane;
@@ -145,44 +165,57 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       }
       const bool diag = CAUSAL && (key0 + KV - 1 > q0);
       const bool partial = diag || (kvalid != ~0ull);
-      const int qrow = q0 + ql;
-      float mloc = NEG;
       if (partial) {
+        const int qrow = q0 + ql;
+        const unsigned lo = (unsigned)(kvalid >> (4 * h)), hi = (unsigned)(kvalid >> (32 + 4 * h));
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+          const unsigned word = s ? hi : lo;           // bit (r&3) + 8(r>>2) of `word` = key 32s + 4h + ...
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int kl = 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;
-            bool ok = (kvalid >> kl) & 1ull;
-            if (CAUSAL) ok = ok && (key0 + kl <= qrow);
+            const int kb = (r & 3) + 8 * (r >> 2);
+            bool ok = (word >> kb) & 1u;
+            if (CAUSAL) ok = ok && (key0 + 32 * s + 4 * h + kb <= qrow);
             st[s][r] = ok ? st[s][r] : NEG;
           }
+        }
+        asm volatile("" ::: "memory");                 // keep this block a real branch (no if-conversion)
       }
+      float mloc = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[s][r]);
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, st[0][r]), st[1][r]);   // v_max3_f32
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run, mloc);
-      const float alpha = exp2f((m_run - m_new) * c2);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
       const float mc = m_new * c2;
       float lsum = 0.f;
+      // exp2(NEG*c2 - mc) underflows to exactly 0 unless the whole row is still masked (m_new == NEG):
+      // then every entry would read exp2(0) = 1, so zero the row explicitly in that (rare) case.
+      const float live = (m_new > 0.5f * NEG) ? 1.f : 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float e = exp2f(st[s][r] * c2 - mc);
-          if (partial) e = (st[s][r] <= NEG) ? 0.f : e;
+          const float e = __builtin_amdgcn_exp2f(st[s][r] * c2 - mc);
           st[s][r] = e;
           lsum += e;
         }
+      if (partial && live == 0.f) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
+        lsum = 0.f;
+      }
       l_run = l_run * alpha + lsum;
       m_run = m_new;
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
-      // ---- O^T += V^T . P^T ; P^T fragment of k-step (s, s2) = bf16(st[s][8*s2 .. 8*s2+7])
+      // ---- O^T += V^T . P^T ; P^T fragment of k-step (s, s2) = bf16(st[s][8*s2 .. 8*s2+7]).
+      // Transposed V reads go through inline asm (tr_read_asm) so the compiler does not drain the
+      // in-flight LDS-DMA of the next tile in front of them; one explicit lgkmcnt(0) per batch of 8.
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -191,17 +224,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[s][8 * s2 + j];
           const int roff = (32 * s + 16 * s2) * ROWB;   // key rows for elements j=0..3 ; +8 rows for j=4..7
+          s16x4 lo[DT], hi[DT];
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff + 8 * ROWB));
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[dt], 0, 0, 0);
+            lo[dt] = tr_read_asm(vb + v_rd[dt] + roff);
+            hi[dt] = tr_read_asm(vb + v_rd[dt] + roff + 8 * ROWB);
           }
+          lds_wait_all();
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo[dt], hi[dt]), pf, ot[dt], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -309,10 +341,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
   constexpr int D = 128, ROWB = 256;
-  constexpr int K_OFF = 0;                                         // K tile 32 KB (V lives in registers)
-  constexpr int QT_OFF = BK_KEYS * ROWB;                           // [2][Q tile 8 KB | dO tile 8 KB]
+  constexpr int K_OFF = 0, V_OFF = BK_KEYS * ROWB;                 // 32 KB each
+  constexpr int QT_OFF = 2 * BK_KEYS * ROWB;                       // [2][Q tile 8 KB | dO tile 8 KB]
   constexpr int QT_BYTES = BQ * ROWB;
   constexpr int T_OFF = QT_OFF + 4 * QT_BYTES;                     // dS^T image [128 keys][32 q] bf16 = 8 KB
   constexpr int L_OFF = T_OFF + BK_KEYS * 64;                      // [2][lse 32 f32 | delta 32 f32]
@@ -329,20 +361,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
 
   const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
   const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
-  // ---- stage K once into LDS (8 pieces of 4 rows per wave); V fragments go straight to registers:
-  // lane (key = wave*32 + ql, h) holds V[key][16ks + 8h .. +8], the B operand of dP = dO.V^T
+  // ---- stage K and V once (8 pieces of 4 rows per wave each)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int piece = 4 * i + wave, r = piece * 4 + sr;
     const int key = min(k0 + r, p.S - 1);
     glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, smem + K_OFF + piece * 1024);
-  }
-  bf16x8 vreg[8];
-  {
-    const int vkey = min(k0 + wave * 32 + ql, p.S - 1);
-    const bf16* vp = vbase + (int64_t)vkey * p.ldv + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) vreg[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+    glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
   }
   const int nqb = (p.S + BQ - 1) / BQ;
   const int qb0 = CAUSAL ? (k0 / BQ) : 0;
@@ -361,10 +386,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       glds16(qbase + (int64_t)qr * p.ldq + (sp ^ sw2(r)) * 8, qt + piece * 1024);
       glds16(dobase + (int64_t)qr * p.lddo + (sp ^ sw2(r)) * 8, qt + QT_BYTES + piece * 1024);
     }
-    if (tid < 64) {
-      const int qr = min(qb * BQ + (tid & 31), p.S - 1);
-      const float* src = (tid < 32 ? p.lse : p.delta) + ((int64_t)b * p.Hq + hq) * p.S + qr;
-      reinterpret_cast<float*>(smem + L_OFF)[buf * 64 + tid] = *src;
+    if (wave == 0) {     // lse[32] | delta[32] of this (head, q-block): one 4-byte LDS-DMA per lane
+      const int qr = min(qb * BQ + (lane & 31), p.S - 1);
+      const float* src = (lane < 32 ? p.lse : p.delta) + ((int64_t)b * p.Hq + hq) * p.S + qr;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(smem + L_OFF + buf * 256), 4, 0, 0);
     }
   };
 
@@ -431,8 +457,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + K_OFF + kv_rd[ks]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);
       const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_rd[ks]);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vreg[ks], pacc, 0, 0, 0);
-      if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // bound the live range of hoisted fragment loads
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + kv_rd[ks]);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
     }
     // ---- P = exp(S*scale - lse), dS = scale * P * (dP - delta); rows q = (r&3) + 8(r>>2) + 4h
     bf16x8 pb[2], dsb[2];
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
         const int qrow = q0 + 8 * g + 4 * h + e;
         bool ok = key_ok && qrow < p.S;
         if (CAUSAL) ok = ok && (key <= qrow);
-        const float pv = ok ? exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
+        const float pv = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
         const float ds = pv * (pacc[r] - d4[e]) * p.scale;
         pb[r >> 3][r & 7] = (bf16)pv;
         dsb[r >> 3][r & 7] = (bf16)ds;
@@ -462,45 +488,63 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBwdArgs p) {
     }
     // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+      s16x4 ra[4][2], rb[4][2];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          ra[dt][e] = tr_read_asm(dot + qt_rd[dt][e] + 16 * s * ROWB);
+          rb[dt][e] = tr_read_asm(qt + qt_rd[dt][e] + 16 * s * ROWB);
+        }
+      lds_wait_all();
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dot + qt_rd[dt][0] + 16 * s * ROWB));
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(dot + qt_rd[dt][1] + 16 * s * ROWB));
-        const bf16x8 dot_f = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot_f, pb[s], dvt[dt], 0, 0, 0);
-        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qt + qt_rd[dt][0] + 16 * s * ROWB));
-        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qt + qt_rd[dt][1] + 16 * s * ROWB));
-        const bf16x8 qt_f = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_f, dsb[s], dkt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ra[dt][0], ra[dt][1]), pb[s], dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(rb[dt][0], rb[dt][1]), dsb[s], dkt[dt], 0, 0, 0);
       }
-    __syncthreads();   // dS^T image complete
+    }
+    // raw barrier: __syncthreads() would add vmcnt(0) and drain the in-flight DMA and atomics
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // dS^T image complete
     // ---- dQ[:, 32*wave .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
     f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + T_OFF + t_rd[0] + 16 * s * 64));
-      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + T_OFF + t_rd[1] + 16 * s * 64));
-      const bf16x8 dsf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-      const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + K_OFF + kt_rd[0] + 16 * s * ROWB));
-      const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + K_OFF + kt_rd[1] + 16 * s * ROWB));
-      const bf16x8 ktf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-      dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, ktf, dq, 0, 0, 0);
+    for (int sh = 0; sh < 2; ++sh) {
+      s16x4 ta[4][2], tk[4][2];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int s = 4 * sh + s4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          ta[s4][e] = tr_read_asm(smem + T_OFF + t_rd[e] + 16 * s * 64);
+          tk[s4][e] = tr_read_asm(smem + K_OFF + kt_rd[e] + 16 * s * ROWB);
+        }
+      }
+      lds_wait_all();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ta[s4][0], ta[s4][1]), join8(tk[s4][0], tk[s4][1]), dq, 0, 0, 0);
     }
     {
-      float* dqp = p.dq_acc + (((int64_t)b * p.S + q0) * p.Hq + hq) * D + 32 * wave + ql;
+      // 16 no-return fp32 atomics per wave, ALWAYS issued (rows past the end add 0 to the last valid row)
+      // so the counted wait below is exact.
+      float* dqp = p.dq_acc + (((int64_t)b * p.S) * p.Hq + hq) * D + 32 * wave + ql;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (q0 + qi < p.S) atomicAdd(dqp + (int64_t)qi * p.Hq * D, dq[r]);
+        const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = qi < p.S;
+        atomicAdd(dqp + (int64_t)min(qi, p.S - 1) * p.Hq * D, ok ? dq[r] : 0.f);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // next Q/dO tile landed; T and the current tile are free again
+    // vmcnt counts loads, LDS-DMA and atomics in issue order: the next tile's DMA (issued at the top of
+    // this iteration) is older than the 16 atomics, so vmcnt(16) retires the DMA and leaves the atomics
+    // in flight across the barrier (a vmcnt(0) here cost ~3000 cycles per iteration waiting for them).
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // next Q/dO tile landed; T and the current tile are free again
   }
 
   // ---- epilogue: dK^T/dV^T [d][key]: lane owns key, 4 consecutive d per register group
@@ -553,7 +597,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask,
                 (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
-  constexpr int LDS = BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
+  constexpr int LDS = 2 * BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
   static bool configured = false;
   if (!configured) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

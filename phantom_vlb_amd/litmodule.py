@@ -222,12 +222,15 @@ class VLBLitModule(_Base):
     def configure_optimizers(self):
         """reference :345-379: AdamW over the trainables + CosineAnnealingLR stepped every step."""
         cfg = self.config
+        from .flat import FlatTrainables
+        if getattr(self, "flat", None) is None:
+            self.flat = FlatTrainables(self)          # masters / bf16 copies / grads / moments -> flat buffers
         named = self.trainable_named_parameters()
         bf16_copies = {n: self.head.compute[n] for n in HEAD_PARAMS}
         if self.lora is not None:
             bf16_copies.update(self.lora.compute_copies())
         self.optimizer = VlbAdamW(named, bf16_copies, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
-                                  weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val)
+                                  weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val, flat=self.flat)
         if self.lora is not None:
             self.optimizer.post_step.append(self.lora.refresh)
         self.lr_scheduler_args = {"last_epoch": cfg.last_epoch, "T_max": cfg.t_max}

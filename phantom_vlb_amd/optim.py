@@ -20,7 +20,7 @@ def _stream():
 
 class VlbAdamW(torch.optim.Optimizer):
     def __init__(self, named_params, bf16_copies: dict, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 max_norm: float = 0.0):
+                 max_norm: float = 0.0, flat=None):
         named_params = list(named_params)
         self.names = [n for n, _ in named_params]
         params = [p for _, p in named_params]
@@ -29,8 +29,13 @@ class VlbAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.bf16 = [bf16_copies.get(n) for n in self.names]
         self.max_norm = float(max_norm)
-        self.m = [torch.zeros_like(p) for p in params]
-        self.v = [torch.zeros_like(p) for p in params]
+        self.flat = flat                  # FlatTrainables: one launch per step instead of one per tensor
+        if flat is not None:
+            self.m = [flat.m[o:o + k].view(shp) for (o, k, shp) in flat.offsets.values()]
+            self.v = [flat.v[o:o + k].view(shp) for (o, k, shp) in flat.offsets.values()]
+        else:
+            self.m = [torch.zeros_like(p) for p in params]
+            self.v = [torch.zeros_like(p) for p in params]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=params[0].device)
         self.step_count = 0
         self.grad_reducer = None      # set by the data-parallel wrapper: callable(list_of_grads)
@@ -47,6 +52,18 @@ class VlbAdamW(torch.optim.Optimizer):
         self.step_count += 1
         st = _stream()
         self.sumsq.zero_()
+        if self.flat is not None:
+            f = self.flat
+            b1, b2 = group["betas"]
+            if self.max_norm > 0:
+                check(lib.vlb_grad_sumsq(f.grad.data_ptr(), f.numel, self.sumsq.data_ptr(), st), "vlb_grad_sumsq")
+            check(lib.vlb_adamw_step(f.master.data_ptr(), f.compute.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(),
+                                     f.v.data_ptr(), f.numel, float(group["lr"]), float(b1), float(b2),
+                                     float(group["eps"]), float(group["weight_decay"]), self.step_count,
+                                     self.sumsq.data_ptr(), self.max_norm, st), "vlb_adamw_step")
+            for fn in self.post_step:
+                fn()
+            return loss
         if self.max_norm > 0:
             for g in grads:
                 check(lib.vlb_grad_sumsq(g.data_ptr(), g.numel(), self.sumsq.data_ptr(), st), "vlb_grad_sumsq")

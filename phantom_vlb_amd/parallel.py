@@ -72,10 +72,15 @@ class FlatGradReducer:
 
 def attach_data_parallel(module, optimizer, group=None):
     """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism."""
-    dicts = [module.head.grads]
-    if getattr(module, "lora", None) is not None:
-        dicts.append(module.lora.grads)
-    reducer = FlatGradReducer(dicts, group)
+    flat = getattr(module, "flat", None)
+    if flat is not None:                     # the optimiser's flat gradient buffer IS the bucket
+        reducer = FlatGradReducer.__new__(FlatGradReducer)
+        reducer.group, reducer.flat = group, flat.grad
+    else:
+        dicts = [module.head.grads]
+        if getattr(module, "lora", None) is not None:
+            dicts.append(module.lora.grads)
+        reducer = FlatGradReducer(dicts, group)
     optimizer.grad_reducer = reducer
     module.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
     module.rank = dist.get_rank(group) if dist.is_initialized() else 0
