@@ -211,8 +211,11 @@ int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (litmodule :345-379 AdamW + CosineAnnealingLR; Trainer gradient_clip_val).
  */
-/* sumsq[0] += sum(g^2)   (fp32 grads; sumsq zeroed by caller once per step) */
-int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* sumsq[0] += sum(g^2)   (fp32 grads; sumsq zeroed by caller once per step).  Two-stage fixed-order
+ * reduction through ws (vlb_sumsq_ws_floats() floats): bit-reproducible, so data-parallel ranks that
+ * hold identical gradients compute identical clip coefficients and stay in lock-step. */
+int vlb_sumsq_ws_floats(void);
+int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, float* ws, void* stream);
 /* fused clip + AdamW on an fp32 master with fp32 moments; writes the bf16 compute copy when
  * param_bf16 != NULL.  clip coefficient = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) read on device
  * (max_norm <= 0 disables clipping).  step counts from 1. */

@@ -52,7 +52,8 @@ SIGNATURES = {
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
     "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],
     "vlb_lora_dx_masked": [P, I, P, I, P, I, I, I, I, F, P, P],
-    "vlb_grad_sumsq": [P, L, P, P],
+    "vlb_sumsq_ws_floats": [],
+    "vlb_grad_sumsq": [P, L, P, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],

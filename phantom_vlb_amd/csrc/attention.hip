@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
       // ---- O^T += V^T . P^T ; P^T fragment of k-step (s, s2) = bf16(st[s][8*s2 .. 8*s2+7]).
-      // Transposed V reads go through inline asm (tr_read_asm) so the compiler does not drain the
-      // in-flight LDS-DMA of the next tile in front of them; one explicit lgkmcnt(0) per batch of 8.
+      // (builtin transposed reads: the compiler pipelines them against the MFMAs; the asm form used in
+      // the backward measured 10 % slower here because every batch needs a full lgkmcnt(0))
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -224,16 +224,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[s][8 * s2 + j];
           const int roff = (32 * s + 16 * s2) * ROWB;   // key rows for elements j=0..3 ; +8 rows for j=4..7
-          s16x4 lo[DT], hi[DT];
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            lo[dt] = tr_read_asm(vb + v_rd[dt] + roff);
-            hi[dt] = tr_read_asm(vb + v_rd[dt] + roff + 8 * ROWB);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff + 8 * ROWB));
+            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo, hi), pf, ot[dt], 0, 0, 0);
           }
-          lds_wait_all();
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo[dt], hi[dt]), pf, ot[dt], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

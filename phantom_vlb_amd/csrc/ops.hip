@@ -374,12 +374,21 @@ __global__ void cast_f2b_kernel(const float* __restrict__ in, bf16* __restrict__
 __global__ void cast_b2f_kernel(const bf16* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
 }
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// two-stage, fixed-order reduction: every rank of a data-parallel job computes bit-identical norms
+constexpr int kSumsqBlocks = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   __shared__ float red[16];
   float s = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] += s;
 }
 __global__ void adamw_kernel(float* __restrict__ p, bf16* __restrict__ pb, const float* __restrict__ g,
                              float* __restrict__ m, float* __restrict__ v, int64_t n, float lr, float b1, float b2,
@@ -551,9 +560,15 @@ extern "C" int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void*
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
-extern "C" int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
-  VLB_REQUIRE(n > 0 && g && sumsq, "grad_sumsq: bad args");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, as_stream(stream), g, n, sumsq);
+extern "C" int vlb_sumsq_ws_floats(void) { return kSumsqBlocks; }
+extern "C" int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, float* ws, void* stream) {
+  VLB_REQUIRE(n > 0 && g && sumsq && ws, "grad_sumsq: bad args");
+  hipStream_t st = as_stream(stream);
+  int64_t nb64 = (n + 1023) / 1024;
+  const int nb = (int)(nb64 > kSumsqBlocks ? kSumsqBlocks : nb64);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, g, n, ws);
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, sumsq);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

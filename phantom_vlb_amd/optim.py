@@ -37,6 +37,7 @@ class VlbAdamW(torch.optim.Optimizer):
             self.m = [torch.zeros_like(p) for p in params]
             self.v = [torch.zeros_like(p) for p in params]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=params[0].device)
+        self.sumsq_ws = torch.zeros(lib.vlb_sumsq_ws_floats(), dtype=torch.float32, device=params[0].device)
         self.step_count = 0
         self.grad_reducer = None      # set by the data-parallel wrapper: callable(list_of_grads)
         self.post_step = []           # callables run after every update (e.g. LoRA derived layouts)
@@ -56,7 +57,7 @@ class VlbAdamW(torch.optim.Optimizer):
             f = self.flat
             b1, b2 = group["betas"]
             if self.max_norm > 0:
-                check(lib.vlb_grad_sumsq(f.grad.data_ptr(), f.numel, self.sumsq.data_ptr(), st), "vlb_grad_sumsq")
+                check(lib.vlb_grad_sumsq(f.grad.data_ptr(), f.numel, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "vlb_grad_sumsq")
             check(lib.vlb_adamw_step(f.master.data_ptr(), f.compute.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(),
                                      f.v.data_ptr(), f.numel, float(group["lr"]), float(b1), float(b2),
                                      float(group["eps"]), float(group["weight_decay"]), self.step_count,
@@ -66,7 +67,7 @@ class VlbAdamW(torch.optim.Optimizer):
             return loss
         if self.max_norm > 0:
             for g in grads:
-                check(lib.vlb_grad_sumsq(g.data_ptr(), g.numel(), self.sumsq.data_ptr(), st), "vlb_grad_sumsq")
+                check(lib.vlb_grad_sumsq(g.data_ptr(), g.numel(), self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "vlb_grad_sumsq")
         b1, b2 = group["betas"]
         for p, g, m, v, pb in zip(params, grads, self.m, self.v, self.bf16):
             check(lib.vlb_adamw_step(p.data_ptr(), None if pb is None else pb.data_ptr(), g.data_ptr(), m.data_ptr(),
