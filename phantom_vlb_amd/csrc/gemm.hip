@@ -684,6 +684,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 
 int g_variant = 1;      // 0: lock-step double buffer, 1: ping-pong wave groups (default)
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
+int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 
 template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3>
 int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
@@ -813,7 +814,30 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   int choice = vec_ok ? vlb_gemm_kernel_choice(M, N, K, K2) : 0;
   if (choice != 0 && g_force_tile == 1 && N % 256 == 0) choice = 1;
   if (choice != 0 && g_force_tile == 2 && N % 128 == 0) choice = 2;
-  if (choice == 1) return launch_tile<256, 256, 2, 4>(a, s);
+  if (choice == 1) {
+    // Tail split: when the 256x256 grid ends in a mostly idle last wave of tiles (e.g. 640 tiles = 2.5
+    // waves for the N=4096 projections at M=10240), run the full waves with 256x256 tiles and the
+    // remaining rows with 256x128 tiles, which fill the chip for one shorter round instead.
+    const int cus = 256, tn = N / 256, tm = (M + 255) / 256;
+    const int tiles = tm * tn, rem = tiles % cus;
+    if (g_tail_split && tiles > cus && rem != 0 && rem <= cus * 5 / 8 && cus % tn == 0) {
+      const int tm1 = (tiles / cus) * (cus / tn);          // row-tiles covered by the full waves
+      const int m1 = tm1 * 256;
+      if (m1 > 0 && m1 < M && M - m1 >= 128) {
+        GemmArgs hi = a, lo = a;
+        hi.M = m1;
+        lo.M = M - m1;
+        lo.A = a.A + (int64_t)m1 * a.lda;
+        lo.C = a.C + (int64_t)m1 * a.ldc;
+        if (a.A2) lo.A2 = a.A2 + (int64_t)m1 * a.lda2;
+        if (a.residual) lo.residual = a.residual + (int64_t)m1 * a.ldr;
+        int rc = launch_tile<256, 256, 2, 4>(hi, s);
+        if (rc != VLB_OK) return rc;
+        return launch_tile<256, 128, 4, 2>(lo, s);
+      }
+    }
+    return launch_tile<256, 256, 2, 4>(a, s);
+  }
   if (choice == 2) return launch_tile<256, 128, 4, 2>(a, s);
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, s, a);
@@ -822,7 +846,11 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
 }
 
 // tuning hooks (not part of the stable ABI): kernel variant / forced tile
-extern "C" void vlb_gemm_set_variant(int variant, int force_tile) { g_variant = variant; g_force_tile = force_tile; }
+extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
+  g_variant = variant & 0xff;
+  g_force_tile = force_tile;
+  g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
+}
 
 extern "C" int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {
   VLB_REQUIRE(in && out && R > 0 && C > 0, "transpose: bad args");

@@ -15,7 +15,7 @@ lib.vlb_gemm_set_variant.restype = None
 
 def main():
     dev = torch.device("cuda:0")
-    variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,4,5".split(","))]
+    variants = [int(v, 0) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,4,5".split(","))]
     shapes = [("qkv", 10240, 6144, 4096), ("o", 10240, 4096, 4096), ("gate_up", 10240, 28672, 4096),
               ("down", 10240, 4096, 14336), ("sq8192", 8192, 8192, 8192), ("vit_fc1", 34620, 4096, 1024)]
     for name, M, N, K in shapes:
