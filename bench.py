@@ -23,6 +23,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
+# L2->fabric bytes of ONE gate/up GEMM launch at B=5, measured offline with rocprofv3 --pmc (separate FETCH_SIZE /
+# WRITE_SIZE passes, gfx950 2x read correction): profiles/r01_gemm_gateup_hbm_traffic.csv.  Only valid for that shape.
+GATEUP_TRAFFIC_BYTES_B5 = 3.904e9
 # algorithmic TFLOP per clip
 TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8}
 
@@ -36,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
     ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-frozen", action="store_true",
+                    help="fsdp.yaml-equivalent: keep 1/N of every frozen decoder layer per rank, all-gather one layer ahead")
     return ap.parse_args()
 
 
@@ -97,6 +102,8 @@ def main():
     m = VLBLitModule(cfg)
     m.world_size, m.rank = world, rank
     m.configure_model()
+    if a.shard_frozen:
+        m.backbone.enable_sharding()
     opt, sch = m.configure_optimizers()
     opt, sch = opt[0], sch[0]["scheduler"]
     if world > 1:
@@ -146,13 +153,15 @@ def main():
                                     if not lora else "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16")
                        if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
-                       "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}",
+                       "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}" + ("+sharded-frozen-weights" if a.shard_frozen else ""),
                        "loss": round(float(loss), 6),
                        "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload], 1),
                        "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<256,256> on gate/up projection "
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<256,256> on gate/up projection "
                          f"[{pM}x{pK}]x[{pN}x{pK}]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": GATEUP_TRAFFIC_BYTES_B5 if (pM, pN, pK) == (10240, 28672, 4096) else None,
+                         "traffic_note": "L2->fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic.csv); algorithmic 6.12e8",
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":

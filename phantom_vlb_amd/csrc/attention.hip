@@ -338,57 +338,67 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
   }
 }
 
+// 8 waves per workgroup: waves 0-3 and 4-7 ("groups") own the SAME 4 x 32 keys but sweep different
+// q-heads of the GQA group, so every SIMD holds two waves whose MFMA / LDS / VALU / atomic phases
+// overlap; K and V tiles are shared, Q/dO/dS^T/lse buffers are per group, and the two partial
+// dK/dV accumulators are summed through LDS once at the end.
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   constexpr int D = 128, ROWB = 256;
-  constexpr int K_OFF = 0, V_OFF = BK_KEYS * ROWB;                 // 32 KB each
-  constexpr int QT_OFF = 2 * BK_KEYS * ROWB;                       // [2][Q tile 8 KB | dO tile 8 KB]
-  constexpr int QT_BYTES = BQ * ROWB;
-  constexpr int T_OFF = QT_OFF + 4 * QT_BYTES;                     // dS^T image [128 keys][32 q] bf16 = 8 KB
-  constexpr int L_OFF = T_OFF + BK_KEYS * 64;                      // [2][lse 32 f32 | delta 32 f32]
+  constexpr int K_OFF = 0, V_OFF = BK_KEYS * ROWB;                 // 32 KB each, shared by both groups
+  constexpr int QT_BYTES = BQ * ROWB;                              // 8 KB
+  constexpr int G_BASE = 2 * BK_KEYS * ROWB;                       // per-group region starts here
+  constexpr int G_QT = 0;                                          // [2][Q tile | dO tile] = 32 KB
+  constexpr int G_T = 4 * QT_BYTES;                                // dS^T image [128 keys][32 q] bf16 = 8 KB
+  constexpr int G_L = G_T + BK_KEYS * 64;                          // [2][lse 32 | delta 32] f32 = 512 B
+  constexpr int G_BYTES = G_L + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w4 = wave & 3;
+  char* gsm = smem + G_BASE + grp * G_BYTES;
   const int kb = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
   const int k0 = kb * BK_KEYS;
-  const int grp = p.Hq / p.Hkv;
+  const int gsz = p.Hq / p.Hkv;
+  const int h_lo = grp == 0 ? 0 : (gsz + 1) / 2;                   // this group's q-heads inside the GQA group
+  const int h_n = grp == 0 ? (gsz + 1) / 2 : gsz / 2;
   const int ql = lane & 31, h = lane >> 5;
   const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
-  const int sr = lane >> 4, sp = lane & 15;    // staging: row within a 4-row piece, slot
+  const int sr = lane >> 4, sp = lane & 15;
 
   const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
   const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
-  // ---- stage K and V once (8 pieces of 4 rows per wave each)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int piece = 4 * i + wave, r = piece * 4 + sr;
+  for (int i = 0; i < 4; ++i) {
+    const int piece = 8 * i + wave, r = piece * 4 + sr;
     const int key = min(k0 + r, p.S - 1);
     glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, smem + K_OFF + piece * 1024);
     glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
   }
   const int nqb = (p.S + BQ - 1) / BQ;
   const int qb0 = CAUSAL ? (k0 / BQ) : 0;
-  const int nq = nqb - qb0;                 // query blocks per head
-  const int total = nq * grp;               // (head, q-block) items of this workgroup
+  const int nq = nqb - qb0;
+  const int my_total = nq * h_n;                                   // items of this group
+  const int total = nq * ((gsz + 1) / 2);                          // loop count (group 0 has >= group 1)
 
   auto stage_q = [&](int buf, int item) {
-    const int hq = hkv * grp + item / nq, qb = qb0 + item % nq;
+    const int hq = hkv * gsz + h_lo + item / nq, qb = qb0 + item % nq;
     const bf16* qbase = p.q + (int64_t)b * p.S * p.ldq + hq * D;
     const bf16* dobase = p.dout + (int64_t)b * p.S * p.lddo + hq * D;
-    char* qt = smem + QT_OFF + buf * 2 * QT_BYTES;
+    char* qt = gsm + G_QT + buf * 2 * QT_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = 4 * i + wave, r = piece * 4 + sr;
+      const int piece = 4 * i + w4, r = piece * 4 + sr;
       const int qr = min(qb * BQ + r, p.S - 1);
       glds16(qbase + (int64_t)qr * p.ldq + (sp ^ sw2(r)) * 8, qt + piece * 1024);
       glds16(dobase + (int64_t)qr * p.lddo + (sp ^ sw2(r)) * 8, qt + QT_BYTES + piece * 1024);
     }
-    if (wave == 0) {     // lse[32] | delta[32] of this (head, q-block): one 4-byte LDS-DMA per lane
+    if (w4 == 0) {
       const int qr = min(qb * BQ + (lane & 31), p.S - 1);
       const float* src = (lane < 32 ? p.lse : p.delta) + ((int64_t)b * p.Hq + hq) * p.S + qr;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                       (void __attribute__((address_space(3)))*)(smem + L_OFF + buf * 256), 4, 0, 0);
+                                       (void __attribute__((address_space(3)))*)(gsm + G_L + buf * 256), 4, 0, 0);
     }
   };
 
@@ -398,19 +408,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
 
-  if (total > 0) stage_q(0, 0);
+  if (my_total > 0) stage_q(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // lane-constant LDS offsets
-  const int krow = wave * 32 + ql;                       // this lane's key row inside the K/V tiles
-  int kv_rd[8];                                          // row reads of K/V: chunk 2ks+h
+  const int krow = w4 * 32 + ql;
+  int kv_rd[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) kv_rd[ks] = krow * ROWB + (((2 * ks + h) ^ sw2(krow)) << 4);
-  int q_rd[8];                                           // row reads of Q/dO tiles (row ql)
+  int q_rd[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) q_rd[ks] = ql * ROWB + (((2 * ks + h) ^ sw2(ql)) << 4);
-  // transposed reads of the Q/dO tiles: rows 16s + 8e + 4h + tq, chunk 4dt + 2g1 + (tp>>1)
   int qt_rd[4][2];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
@@ -419,14 +427,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
       const int r = 8 * e + 4 * h + tq;
       qt_rd[dt][e] = r * ROWB + (((4 * dt + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
     }
-  // transposed reads of K for dQ (B operand): rows 16s + 8h + 4e + tq, chunk 4*wave + 2g1 + (tp>>1)
   int kt_rd[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int r = 8 * h + 4 * e + tq;
-    kt_rd[e] = r * ROWB + (((4 * wave + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
+    kt_rd[e] = r * ROWB + (((4 * w4 + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
   }
-  // transposed reads of T (dS^T image, 64-byte rows): rows 16s + 8h + 4e + tq, cols 16g1 + 4tp
   int t_rd[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) t_rd[e] = (8 * h + 4 * e + tq) * 64 + (16 * g1 + 4 * tp) * 2;
@@ -438,115 +444,128 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
 
   for (int item = 0; item < total; ++item) {
     const int cur = item & 1;
-    if (item + 1 < total) stage_q(cur ^ 1, item + 1);
-    const int hq = hkv * grp + item / nq, qb = qb0 + item % nq;
-    const char* qt = smem + QT_OFF + cur * 2 * QT_BYTES;
+    const bool active = item < my_total;            // group-uniform; inactive waves only keep the barriers
+    if (item + 1 < my_total) stage_q(cur ^ 1, item + 1);
+    const int hq = hkv * gsz + h_lo + item / nq, qb = qb0 + item % nq;
+    const char* qt = gsm + G_QT + cur * 2 * QT_BYTES;
     const char* dot = qt + QT_BYTES;
-    const float* ls = reinterpret_cast<const float*>(smem + L_OFF) + cur * 64;
+    const float* ls = reinterpret_cast<const float*>(gsm + G_L) + cur * 64;
     const int q0 = qb * BQ;
-
-    // ---- S = Q.K^T and dP = dO.V^T  (key on lane)
-    f32x16 sacc, pacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + q_rd[ks]);
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + K_OFF + kv_rd[ks]);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);
-      const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_rd[ks]);
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + kv_rd[ks]);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
-    }
-    // ---- P = exp(S*scale - lse), dS = scale * P * (dP - delta); rows q = (r&3) + 8(r>>2) + 4h
     bf16x8 pb[2], dsb[2];
+    if (active) {
+      // ---- S = Q.K^T and dP = dO.V^T  (key on lane)
+      f32x16 sacc, pacc;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * h);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * h);
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const int qrow = q0 + 8 * g + 4 * h + e;
-        bool ok = key_ok && qrow < p.S;
-        if (CAUSAL) ok = ok && (key <= qrow);
-        const float pv = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
-        const float ds = pv * (pacc[r] - d4[e]) * p.scale;
-        pb[r >> 3][r & 7] = (bf16)pv;
-        dsb[r >> 3][r & 7] = (bf16)ds;
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + q_rd[ks]);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + K_OFF + kv_rd[ks]);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sacc, 0, 0, 0);
+        const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_rd[ks]);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + kv_rd[ks]);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
       }
-    }
-    // ---- dS^T image: row = key (krow), cols q = 8g + 4h + {0..3}  (8-byte stores)
+      // ---- P = exp(S*scale - lse), dS = scale * P * (dP - delta); rows q = (r&3) + 8(r>>2) + 4h
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 t;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
-      *reinterpret_cast<bf16x4*>(smem + T_OFF + krow * 64 + (8 * g + 4 * h) * 2) = t;
-    }
-    // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      s16x4 ra[4][2], rb[4][2];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          ra[dt][e] = tr_read_asm(dot + qt_rd[dt][e] + 16 * s * ROWB);
-          rb[dt][e] = tr_read_asm(qt + qt_rd[dt][e] + 16 * s * ROWB);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int qrow = q0 + 8 * g + 4 * h + e;
+          bool ok = key_ok && qrow < p.S;
+          if (CAUSAL) ok = ok && (key <= qrow);
+          const float pv = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
+          const float ds = pv * (pacc[r] - d4[e]) * p.scale;
+          pb[r >> 3][r & 7] = (bf16)pv;
+          dsb[r >> 3][r & 7] = (bf16)ds;
         }
-      lds_wait_all();
+      }
+      // ---- dS^T image: row = key (krow), cols q = 8g + 4h + {0..3}  (8-byte stores)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ra[dt][0], ra[dt][1]), pb[s], dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(rb[dt][0], rb[dt][1]), dsb[s], dkt[dt], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
+        *reinterpret_cast<bf16x4*>(gsm + G_T + krow * 64 + (8 * g + 4 * h) * 2) = t;
+      }
+      // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s16x4 ra[4][2], rb[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            ra[dt][e] = tr_read_asm(dot + qt_rd[dt][e] + 16 * s * ROWB);
+            rb[dt][e] = tr_read_asm(qt + qt_rd[dt][e] + 16 * s * ROWB);
+          }
+        lds_wait_all();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ra[dt][0], ra[dt][1]), pb[s], dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(rb[dt][0], rb[dt][1]), dsb[s], dkt[dt], 0, 0, 0);
+        }
       }
     }
     // raw barrier: __syncthreads() would add vmcnt(0) and drain the in-flight DMA and atomics
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // dS^T image complete
-    // ---- dQ[:, 32*wave .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
-    f32x16 dq;
+    __builtin_amdgcn_s_barrier();   // dS^T images complete
+    if (active) {
+      // ---- dQ[:, 32*w4 .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
+      f32x16 dq;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
-    for (int sh = 0; sh < 2; ++sh) {
-      s16x4 ta[4][2], tk[4][2];
+      for (int sh = 0; sh < 2; ++sh) {
+        s16x4 ta[4][2], tk[4][2];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int s = 4 * sh + s4;
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int s = 4 * sh + s4;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          ta[s4][e] = tr_read_asm(smem + T_OFF + t_rd[e] + 16 * s * 64);
-          tk[s4][e] = tr_read_asm(smem + K_OFF + kt_rd[e] + 16 * s * ROWB);
+          for (int e = 0; e < 2; ++e) {
+            ta[s4][e] = tr_read_asm(gsm + G_T + t_rd[e] + 16 * s * 64);
+            tk[s4][e] = tr_read_asm(smem + K_OFF + kt_rd[e] + 16 * s * ROWB);
+          }
         }
-      }
-      lds_wait_all();
+        lds_wait_all();
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ta[s4][0], ta[s4][1]), join8(tk[s4][0], tk[s4][1]), dq, 0, 0, 0);
-    }
-    {
+        for (int s4 = 0; s4 < 4; ++s4)
+          dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ta[s4][0], ta[s4][1]), join8(tk[s4][0], tk[s4][1]), dq, 0, 0, 0);
+      }
       // 16 no-return fp32 atomics per wave, ALWAYS issued (rows past the end add 0 to the last valid row)
-      // so the counted wait below is exact.
-      float* dqp = p.dq_acc + (((int64_t)b * p.S) * p.Hq + hq) * D + 32 * wave + ql;
+      float* dqp = p.dq_acc + (((int64_t)b * p.S) * p.Hq + hq) * D + 32 * w4 + ql;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = qi < p.S;
         atomicAdd(dqp + (int64_t)min(qi, p.S - 1) * p.Hq * D, ok ? dq[r] : 0.f);
       }
+      // the next tile's DMA (issued at the top of this iteration) is older than the 16 atomics:
+      // vmcnt(16) retires it and leaves the atomics in flight across the barrier.
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // vmcnt counts loads, LDS-DMA and atomics in issue order: the next tile's DMA (issued at the top of
-    // this iteration) is older than the 16 atomics, so vmcnt(16) retires the DMA and leaves the atomics
-    // in flight across the barrier (a vmcnt(0) here cost ~3000 cycles per iteration waiting for them).
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // next Q/dO tile landed; T and the current tile are free again
   }
 
-  // ---- epilogue: dK^T/dV^T [d][key]: lane owns key, 4 consecutive d per register group
-  if (key < p.S) {
+  // ---- sum the two groups' dK^T/dV^T through LDS (all tiles are dead now), group 0 writes the result
+  float* red = reinterpret_cast<float*>(smem);       // [w4][8 tiles][16 regs][64 lanes] fp32 = 128 KB
+  if (grp == 1) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[((w4 * 8 + dt) * 16 + r) * 64 + lane] = dkt[dt][r];
+        red[((w4 * 8 + 4 + dt) * 16 + r) * 64 + lane] = dvt[dt][r];
+      }
+  }
+  __syncthreads();
+  if (grp == 0 && key < p.S) {
     bf16* dkp = p.dk + ((int64_t)b * p.S + key) * p.lddk + hkv * D;
     bf16* dvp = p.dv + ((int64_t)b * p.S + key) * p.lddv + hkv * D;
 #pragma unroll
@@ -555,7 +574,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs p) {
       for (int g = 0; g < 4; ++g) {
         bf16x4 a, c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = (bf16)dkt[dt][4 * g + e]; c[e] = (bf16)dvt[dt][4 * g + e]; }
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          a[e] = (bf16)(dkt[dt][r] + red[((w4 * 8 + dt) * 16 + r) * 64 + lane]);
+          c[e] = (bf16)(dvt[dt][r] + red[((w4 * 8 + 4 + dt) * 16 + r) * 64 + lane]);
+        }
         *reinterpret_cast<bf16x4*>(dkp + 32 * dt + 8 * g + 4 * h) = a;
         *reinterpret_cast<bf16x4*>(dvp + 32 * dt + 8 * g + 4 * h) = c;
       }
@@ -595,7 +618,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask,
                 (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
-  constexpr int LDS = 2 * BK_KEYS * 256 + 4 * BQ * 256 + BK_KEYS * 64 + 2 * 64 * 4;
+  constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
   static bool configured = false;
   if (!configured) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -604,8 +627,8 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
     configured = true;
   }
   dim3 grid((S + BK_KEYS - 1) / BK_KEYS, Hkv, B);
-  if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), LDS, st, a);
-  else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), LDS, st, a);
+  if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
+  else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
   VLB_LAUNCH_CHECK();
   const int64_t total = (int64_t)B * S * (Hq * D / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;

@@ -88,3 +88,28 @@ def test_sharded_layer_store_same_result(dev, lora):
         outs.append((float(loss), m.flat.grad.clone()))
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_upstream_named_safetensors_checkpoint_loads(dev, tmp_path):
+    """model_path = a local directory of *.safetensors with UPSTREAM tensor names (what a real
+    VideoLLaMA2 checkpoint looks like): same prediction as handing the state dict in directly."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vlb_oracle as O
+    from safetensors.torch import save_file
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.synthetic import synthetic_batch
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=21))
+    backbone = {k: v.to(torch.bfloat16).contiguous() for k, v in p.items() if k.startswith("model.")}
+    keys = sorted(backbone)
+    save_file({k: backbone[k] for k in keys[: len(keys) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: backbone[k] for k in keys[len(keys) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    a = VLBLitModule(_cfg(model_path=str(tmp_path)))
+    a.configure_model(head_state=p)
+    b = VLBLitModule(_cfg())
+    b.configure_model(state_dict=p, head_state=p)
+    batch = synthetic_batch(a.geometry, 2, seed=3, device=a.device)
+    pa = a.validation_step(batch)["brain_preds"]
+    pb = b.validation_step(batch)["brain_preds"]
+    assert torch.equal(pa, pb)
