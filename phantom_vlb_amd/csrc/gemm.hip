@@ -208,7 +208,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
 // S0..S3: how many of the tile's LDS-DMA instructions a wave issues in load slot 0..3 of the 4-interval
 // window that precedes the tile's first read (slot q of group 0 = its segments L0,C0,L1,C1 of tile t;
 // of group 1 = C1 of tile t-1, then L0,C0,L1 of tile t).  S0+S1+S2+S3 = A_LD + B_LD.
-template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3>
+// ABL (timing-only ablations, results are WRONG when non-zero): bit0 skip LDS-DMA in the loop, bit1 skip
+// fragment reads in the loop, bit2 skip the barriers in the loop.
+template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   static_assert(WM * WN == 8 && WM % 2 == 0, "8 waves, groups split along M");
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -298,6 +300,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                     \
     __builtin_amdgcn_sched_barrier(0);                \
   } while (0)
+#define PP_LOOP_BARRIER()                             \
+  do {                                                \
+    if constexpr (!(ABL & 4)) { PP_BARRIER(); } else { __builtin_amdgcn_sched_barrier(0); } \
+  } while (0)
 #define PP_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
 #define PP_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
@@ -311,21 +317,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const char* sb = smem + (kt & 1) * STAGE;
     const int nb = (kt & 1) ^ 1;                       // buffer of tile kt+1 (and of tile kt+2: kt&1)
-    const bool ld1 = kt >= 1 && kt + 1 < nk;           // this window loads tile kt+1
+    const bool ld1 = !(ABL & 1) && kt >= 1 && kt + 1 < nk;   // this window loads tile kt+1
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // ---------------- LOAD segment
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks]);
+      for (int j = 0; j < NT; ++j) if ((ABL & 2) == 0 || kt == 0) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j][ks]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i][ks]);
+      for (int i = 0; i < MT; ++i) if ((ABL & 2) == 0 || kt == 0) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i][ks]);
       if (ld1) {
         if (grp == 0) { if (ks == 0) stage_range(nb, kt + 1, 0, O1); else stage_range(nb, kt + 1, O2, O3); }
         else          { if (ks == 0) stage_range(nb, kt + 1, O1, O2); else stage_range(nb, kt + 1, O3, O4); }
       }
       PP_LGKM0();
       if (ks == 1 && grp == 1 && kt >= 1) PP_VM0();
-      PP_BARRIER();
+      PP_LOOP_BARRIER();
       // ---------------- COMPUTE segment
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -338,219 +344,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
         if (ld1) { if (ks == 0) stage_range(nb, kt + 1, O1, O2); else stage_range(nb, kt + 1, O3, O4); }
       } else {
         if (ks == 0) { if (ld1) stage_range(nb, kt + 1, O2, O3); }
-        else if (kt + 2 < nk) stage_range(kt & 1, kt + 2, 0, O1);   // slot 0 of the NEXT window
+        else if (!(ABL & 1) && kt + 2 < nk) stage_range(kt & 1, kt + 2, 0, O1);   // slot 0 of the NEXT window
       }
       if (ks == 1 && grp == 0 && kt >= 1) PP_VM0();
-      PP_BARRIER();
+      PP_LOOP_BARRIER();
     }
   }
   if (grp == 0) PP_BARRIER();
 #undef PP_BARRIER
+#undef PP_LOOP_BARRIER
 #undef PP_LGKM0
 #undef PP_VM0
-
-  if (p.act == VLB_ACT_SWIGLU_PAIR) {
-    // W rows are interleaved in 16-row blocks [gate_b | up_b]: n-tiles (2j, 2j+1) hold gate and up of the
-    // same 16 output features at the same lane/register positions -> out = silu(gate) * up, N/2 columns.
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * TM + i * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int n = (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4;
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(acc[i][j][e]) * acc[i][j + 1][e]);
-        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * TM + i * 16 + fr;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * TN + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
-      }
-      if (p.act != VLB_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-      }
-      if (p.residual) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong v2: K-tiles of 32 in a 4-deep LDS ring, ONE barrier per tile.
-// Group 0 (waves 0-3) runs  [barrier_p | C_p  L_{p+1}],  group 1 (waves 4-7) runs  [barrier_p | L_p  C_p]:
-// inside every interval the SIMD's matrix pipe sees C_p of group 0 and then C_p of group 1 back to
-// back (64 MFMAs), while the other wave's 12 fragment reads + LDS-DMA issue + waits hide underneath.
-//   tile p lives in ring slot p&3, is read by group 0 in interval p-1 and by group 1 in interval p;
-//   its slot is free after barrier_{p+1}; tile p+4 is DMA'd into it during interval p+1 and retired by
-//   the counted  vmcnt(4)  at the end of interval p+2 (two intervals of flight, never vmcnt(0) in the loop).
-// LDS image of a [rows][32] tile: 64-byte rows, chunk c of row r at slot c ^ h((r>>2)&3), h = {0,2,3,1}:
-// four rows share a 256-byte bank row and every ds_read_b128 lane group lands on 16 distinct slots.
-// ------------------------------------------------------------------------------------------------
-constexpr int BK2 = 32;
-constexpr int ROW2 = BK2 * 2;     // 64 bytes
-__device__ __forceinline__ int swz2(int r) { return (0x1320 >> (((r >> 2) & 3) * 4)) & 3; }   // h = {0,2,3,1}
-__device__ __forceinline__ int lds_off2(int r, int c) { return r * ROW2 + ((c ^ swz2(r)) << 4); }
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
-  static_assert(WM * WN == 8 && WM % 2 == 0, "8 waves, groups split along M");
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MT = TM / 16, NT = TN / 16;
-  constexpr int A_BYTES = BM * ROW2, B_BYTES = BN * ROW2;
-  constexpr int STAGE = A_BYTES + B_BYTES;        // 32 KB for 256x256
-  constexpr int A_LD = BM / 128, B_LD = BN / 128;  // one LDS-DMA instruction = 16 rows; 8 waves -> 128 rows
-  constexpr int NLD = A_LD + B_LD;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int nblk = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
-    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  constexpr int GROUP_M = 4;
-  const int band = GROUP_M * p.tiles_n;
-  const int g0 = (pid / band) * GROUP_M;
-  const int gsz = min(p.tiles_m - g0, GROUP_M);
-  const int tm = g0 + (pid % band) % gsz;
-  const int tn = (pid % band) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int grp = wave >> 2;
-
-  // staging: instruction i of this wave fills LDS rows [i*128 + wave*16, +16); lane -> (row l>>2, slot l&3)
-  const int srow = lane >> 2, sslot = lane & 3;
-  const bf16* a_src[A_LD]; const bf16* b_src[B_LD];
-  const bf16* a2_src[A_LD]; const bf16* b2_src[B_LD];
-#pragma unroll
-  for (int i = 0; i < A_LD; ++i) {
-    const int r = i * 128 + wave * 16 + srow;
-    const int c = sslot ^ swz2(r);
-    const int gm = min(m0 + r, p.M - 1);
-    a_src[i] = p.A + (int64_t)gm * p.lda + c * 8;
-    a2_src[i] = p.A2 ? p.A2 + (int64_t)gm * p.lda2 + c * 8 : nullptr;
-  }
-#pragma unroll
-  for (int i = 0; i < B_LD; ++i) {
-    const int r = i * 128 + wave * 16 + srow;
-    const int c = sslot ^ swz2(r);
-    b_src[i] = p.W + (int64_t)(n0 + r) * p.ldw + c * 8;
-    b2_src[i] = p.W2 ? p.W2 + (int64_t)(n0 + r) * p.ldw2 + c * 8 : nullptr;
-  }
-  const int nk1 = p.K / BK2;
-  const int nk = nk1 + p.K2 / BK2;
-
-  auto stage = [&](int kt) {
-    char* base = smem + (kt & 3) * STAGE + wave * 16 * ROW2;
-    const bool first = kt < nk1;
-    const int ko = (first ? kt : kt - nk1) * BK2;
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) glds16((first ? a_src[i] : a2_src[i]) + ko, base + i * 128 * ROW2);
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) glds16((first ? b_src[i] : b2_src[i]) + ko, base + A_BYTES + i * 128 * ROW2);
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_off[MT], b_off[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) a_off[i] = lds_off2(wm * TM + i * 16 + fr, fq);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) b_off[j] = A_BYTES + lds_off2(wn * TN + j * 16 + fr, fq);
-
-#define PP_BARRIER()                                  \
-  do {                                                \
-    __builtin_amdgcn_sched_barrier(0);                \
-    __builtin_amdgcn_s_barrier();                     \
-    __builtin_amdgcn_sched_barrier(0);                \
-  } while (0)
-#define PP_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
-
-  bf16x8 af[MT], wf[NT];
-  auto load_frags = [&](int kt) {
-    const char* sb = smem + (kt & 3) * STAGE;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j]);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i]);
-  };
-  auto compute = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // end-of-interval wait: tile p+2 must have landed; tile p+3's DMA (NLD instructions) may stay in flight
-  auto retire = [&](bool issued_next) {
-    if (issued_next) {
-      if constexpr (NLD == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-
-  // prologue: tiles 0..2 in flight, all landed before the first read
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_BARRIER();
-  if (grp == 0) { load_frags(0); PP_LGKM0(); }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    PP_BARRIER();                                  // barrier_kt : interval kt begins
-    const bool nxt = kt + 3 < nk;
-    if (nxt) stage(kt + 3);                        // ring slot of tile kt-1, last read in interval kt-1
-    if (grp == 1) {                                // group 1: L_kt before C_kt
-      load_frags(kt);
-      PP_LGKM0();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    compute();                                     // C_kt (single code site for both groups)
-    if (grp == 0) {                                // group 0: L_{kt+1} after C_kt
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) load_frags(kt + 1);
-      PP_LGKM0();
-    }
-    retire(nxt);
-  }
-#undef PP_BARRIER
-#undef PP_LGKM0
 
   if (p.act == VLB_ACT_SWIGLU_PAIR) {
     // W rows are interleaved in 16-row blocks [gate_b | up_b]: n-tiles (2j, 2j+1) hold gate and up of the
@@ -686,11 +490,11 @@ int g_variant = 1;      // 0: lock-step double buffer, 1: ping-pong wave groups 
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 
-template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3>
+template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3, int ABL = 0>
 int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
@@ -698,7 +502,7 @@ int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -722,26 +526,15 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
   }
   constexpr int T = (BM + BN) / 64;     // LDS-DMA instructions per thread per K-tile
-  if (g_variant == 2) return launch_pp<BM, BN, WM, WN, T / 2, 0, T - T / 2, 0>(a, s, LDS);
-  if (g_variant == 3) return launch_pp<BM, BN, WM, WN, T / 4, T / 4, T / 4, T - 3 * (T / 4)>(a, s, LDS);
-  if (g_variant == 4) return launch_pp<BM, BN, WM, WN, 0, T / 2, 0, T - T / 2>(a, s, LDS);
-  if (g_variant == 5) return launch_pp<BM, BN, WM, WN, 3 * T / 8, T / 8, 3 * T / 8, T - 3 * T / 8 - T / 8 - 3 * T / 8>(a, s, LDS);
-  if (g_variant == 6) {
-    constexpr int LDS2 = 4 * (BM + BN) * ROW2;
-    static bool configured2 = false;
-    if (!configured2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp2_kernel<BM, BN, WM, WN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-      if (e != hipSuccess) {
-        vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS2, hipGetErrorString(e));
-        return VLB_ERR_LAUNCH;
-      }
-      configured2 = true;
-    }
-    hipLaunchKernelGGL((gemm_pp2_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS2, s, a);
-    VLB_LAUNCH_CHECK();
-    return VLB_OK;
+  if constexpr (BM == 256 && BN == 256) {   // timing-only ablations of the 256x256 kernel (wrong results!)
+    if (g_variant == 0x11) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 1>(a, s, LDS);
+    if (g_variant == 0x12) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 2>(a, s, LDS);
+    if (g_variant == 0x14) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 4>(a, s, LDS);
+    if (g_variant == 0x13) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 3>(a, s, LDS);
+    if (g_variant == 0x17) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 7>(a, s, LDS);
+    if (g_variant == 0x16) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0, 6>(a, s, LDS);
   }
+  if (g_variant >= 0x10) return launch_pp<BM, BN, WM, WN, T, 0, 0, 0>(a, s, LDS);   // ablations exist for 256x256 only
   if (g_variant != 0) {
     vlb_set_error("gemm: unknown kernel variant %d", g_variant);
     return VLB_ERR_INVALID;
