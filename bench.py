@@ -82,9 +82,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # VLB_FORCE_DIST=1 runs the multi-process code path (RCCL init, flat-bucket all-reduce, barriers)
+    # even at world size 1 - used to rehearse `--gpus N` on a one-GPU box.
+    use_dist = world > 1 or os.environ.get("VLB_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group(os.environ.get("VLB_DIST_BACKEND", "nccl"), device_id=dev)
     from phantom_vlb_amd import ops
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
@@ -106,9 +111,11 @@ def main():
         m.backbone.enable_sharding()
     opt, sch = m.configure_optimizers()
     opt, sch = opt[0], sch[0]["scheduler"]
-    if world > 1:
-        from phantom_vlb_amd.parallel import attach_data_parallel
-        attach_data_parallel(m, opt)
+    if use_dist:
+        from phantom_vlb_amd.parallel import attach_data_parallel, broadcast_parameters
+        red = attach_data_parallel(m, opt)
+        red.force = True                      # all-reduce even at world size 1 (rehearsal)
+        broadcast_parameters([m.flat.master, m.flat.compute])
     g = m.geometry
     batch = synthetic_batch(g, B, seed=1234 + rank, device=dev)
 
@@ -119,7 +126,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +141,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.disable_gemm_probe()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -168,7 +175,7 @@ def main():
             v, cores, sample = cpu_baseline(g, cfg.num_target)
             out["cpu_baseline"] = {"value": round(v, 6), "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -65,8 +65,10 @@ class FlatGradReducer:
             d[k] = view                     # kernels write straight into the bucket from now on
             off += n
 
+    force = False     # rehearsal switch: reduce even when the group has a single rank
+
     def __call__(self, grads=None):
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
@@ -89,7 +91,7 @@ def attach_data_parallel(module, optimizer, group=None):
 
 def broadcast_parameters(tensors, src: int = 0, group=None):
     """fsdp_sync_module_states equivalent: make every rank start from rank `src`'s trainables."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         for t in tensors:
             dist.broadcast(t, src=src, group=group)
 
