@@ -231,13 +231,28 @@ __global__ void drop_cls_kernel(const bf16* __restrict__ tok, bf16* __restrict__
 }
 
 // ------------------------------------------------------------------ connector stencils (NHWC)
-__global__ void dwconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w9, bf16* __restrict__ y, int H,
-                                 int W, int C, int64_t total) {
-  const int cpr = C >> 3;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (idx % cpr) * 8;
-    const int wx = (idx / cpr) % W, hy = (idx / ((int64_t)cpr * W)) % H;
-    const int64_t n = idx / ((int64_t)cpr * W * H);
+// LDS-tiled: one block = one image x 32 channels.  The whole H x W plane of those channels (64 bytes per
+// position) is staged once in LDS and every output reads its 9 taps from there, so HBM sees each input
+// byte once instead of nine L2 re-reads.  grid (C/32, N), block 256; LDS = H*W*64 bytes.
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w9,
+                                                        bf16* __restrict__ y, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) char plane[];   // [H*W][4 chunks][16 B]
+  const int c0 = blockIdx.x * 32;
+  const int64_t n = blockIdx.y;
+  const int HW = H * W;
+  const bf16* xb = x + n * HW * (int64_t)C + c0;
+  for (int i = threadIdx.x; i < HW * 4; i += 256) {
+    const int p = i >> 2, ch = i & 3;
+    *reinterpret_cast<bf16x8*>(plane + i * 16) = *reinterpret_cast<const bf16x8*>(xb + (int64_t)p * C + ch * 8);
+  }
+  const int ch = threadIdx.x & 3;
+  float k[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) load8(w9 + (int64_t)t * C + c0 + ch * 8, k[t]);
+  __syncthreads();
+  bf16* yb = y + n * HW * (int64_t)C + c0 + ch * 8;
+  for (int p = threadIdx.x >> 2; p < HW; p += 64) {
+    const int hy = p / W, wx = p % W;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
@@ -245,13 +260,11 @@ __global__ void dwconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restr
       for (int dx = -1; dx <= 1; ++dx) {
         const int yy = hy + dy, xx = wx + dx;
         if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        float v[8], k[8];
-        load8(x + ((n * H + yy) * W + xx) * C + c, v);
-        load8(w9 + ((dy + 1) * 3 + (dx + 1)) * C + c, k);
+        float v[8]; load8(reinterpret_cast<const bf16*>(plane + ((yy * W + xx) * 4 + ch) * 16), v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += v[i] * k[i];
+        for (int i = 0; i < 8; ++i) acc[i] += v[i] * k[(dy + 1) * 3 + (dx + 1)][i];
       }
-    store8(y + ((n * H + hy) * W + wx) * C + c, acc);
+    store8(yb + (int64_t)p * C, acc);
   }
 }
 // block = 64 channel chunks x 4 row groups; grid (C/512, N)
@@ -497,10 +510,17 @@ extern "C" int vlb_drop_cls(const void* tokens, void* out, int N, int G, int D, 
   return VLB_OK;
 }
 extern "C" int vlb_dwconv3x3(const void* x, const void* w, void* y, int N, int H, int W, int C, void* stream) {
-  VLB_REQUIRE(N > 0 && H > 0 && W > 0 && C % 8 == 0, "dwconv3x3: bad shape");
-  const int64_t total = (int64_t)N * H * W * (C / 8);
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), (const bf16*)x,
-                     (const bf16*)w, (bf16*)y, H, W, C, total);
+  VLB_REQUIRE(N > 0 && H > 0 && W > 0 && C % 32 == 0, "dwconv3x3: bad shape (C must be a multiple of 32)");
+  const int lds = H * W * 64;
+  VLB_REQUIRE(lds <= 160 * 1024, "dwconv3x3: plane of %dx%d positions does not fit in LDS", H, W);
+  static int reserved = 0;
+  if (lds > reserved) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { vlb_set_error("dwconv3x3: LDS reservation failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+    reserved = lds;
+  }
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(C / 32, N), dim3(256), lds, as_stream(stream), (const bf16*)x, (const bf16*)w,
+                     (bf16*)y, H, W, C);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

@@ -275,7 +275,7 @@ def test_vit_assemble_and_drop_cls(dev):
 
 def test_dwconv_se_im2col(dev):
     from phantom_vlb_amd import ops
-    N, H, C = 3, 6, 64
+    N, H, C = 3, 13, 96
     x = _r(N * H * H, C, dev=dev)
     w = torch.randn(C, 1, 3, 3) * 0.3
     y = ops.dwconv3x3(x, w.flatten(1).t().contiguous().to(BF).to(dev), N, H, H, C)
