@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
     ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pack", action="store_true",
+                    help="keep the dense [B, max_len] token layout (compute the padded tail rows too)")
     ap.add_argument("--shard-frozen", action="store_true",
                     help="fsdp.yaml-equivalent: keep 1/N of every frozen decoder layer per rank, all-gather one layer ahead")
     return ap.parse_args()
@@ -101,7 +103,7 @@ def main():
         lora_r=16 if lora else None, lora_alpha=32 if lora else None, lora_dropout=0.1 if lora else None,
         dropout_rate=0.1, num_target=2048 if a.geometry == "7b" else 128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999],
         eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000,
-        geometry=a.geometry)
+        geometry=a.geometry, pack_tokens=not a.no_pack)
     import warnings
     warnings.simplefilter("ignore")
     m = VLBLitModule(cfg)
@@ -118,6 +120,11 @@ def main():
         broadcast_parameters([m.flat.master, m.flat.compute])
     g = m.geometry
     batch = synthetic_batch(g, B, seed=1234 + rank, device=dev)
+    # pixels / targets / weights are resident in HBM; the ids and padvals (20 KB) stay on the host, as a
+    # DataLoader hands them over, so the step can size its unpadded row layout without a device sync
+    batch["language"], batch["padvals"] = batch["language"].cpu(), batch["padvals"].cpu()
+    lay = m.backbone.row_layout(batch["language"], batch["padvals"]) if m.pack_tokens else None
+    rows_run, rows_dense = (lay.rows if lay is not None else B * g.max_len), B * g.max_len
 
     def step():
         loss = m.training_step(batch)
@@ -162,8 +169,11 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
                        "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}" + ("+sharded-frozen-weights" if a.shard_frozen else ""),
                        "loss": round(float(loss), 6),
-                       "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload], 1),
-                       "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] / PEAK_BF16_TFLOPS, 4)},
+                       "token_rows": {"computed": rows_run, "padded_layout": rows_dense,
+                                      "note": "padded tail rows (ids == 0) are not computed, like the reference's flash-attn unpadding; results identical"},
+                       # executed FLOPs: the per-clip figure scaled by the rows actually run (conservative: the vision tower is not reduced)
+                       "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense, 1),
+                       "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<256,256> on gate/up projection "
                          f"[{pM}x{pK}]x[{pN}x{pK}]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),

@@ -75,17 +75,22 @@ int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream);
  *   Hkv heads; out [B,S,Hq,D] stride ldo.  key_mask: [B,S] bytes (1 = attend) or NULL.
  *   lse: [B,Hq,S] fp32 log-sum-exp (natural log, of scaled scores) or NULL; needed by bwd.
  *   D in {64,128}.
+ *   Packed (unpadded) rows, the flash-attn varlen path of modeling_mistral.py (_upad_input): when
+ *   cu_rows != NULL (int32 [B+1] device prefix sums), clip b owns rows [cu_rows[b], cu_rows[b+1]) of
+ *   q/k/v/out/key_mask and S is the LONGEST clip (grid size; lse/delta stay [B,Hq,S]).  NULL = dense.
  */
 int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                       float* lse, const uint8_t* key_mask, int B, int S, int Hq, int Hkv, int D, int causal,
-                      float scale, void* stream);
+                      float scale, const int* cu_rows, void* stream);
 
 /* Backward of the above. dq/dk/dv have the layout/strides of q/k/v.  delta: [B,Hq,S] fp32 workspace.
- * dq_acc: [B,S,Hq,D] fp32 workspace (zeroed by the call). */
+ * dq_acc: [rows,Hq,D] fp32 workspace (zeroed by the call).  total_rows = cu_rows[B] (host copy;
+ * ignored when cu_rows == NULL, where rows = B*S). */
 int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
                       int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,
                       int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B, int S,
-                      int Hq, int Hkv, int D, int causal, float scale, void* stream);
+                      int Hq, int Hkv, int D, int causal, float scale, const int* cu_rows, int total_rows,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row normalisations (HBM-bound, 16-byte vector loads, fp32 statistics).
@@ -106,9 +111,10 @@ int vlb_layernorm_fwd(const void* x, const void* w, const void* b, const void* r
  * Decoder element-wise ops.
  */
 /* apply_rotary_pos_emb, modeling_mistral.py:51-81, in place on `heads` heads of width D starting at x
- * (token stride ld). cos/sin: [S, D/2] fp32 tables (positions 0..S-1).  sign=+1 forward, -1 backward. */
-int vlb_rope_inplace(void* x, int ld, const float* cos_t, const float* sin_t, int B, int S, int heads, int D,
-                     int sign, void* stream);
+ * (token stride ld). cos/sin: [S, D/2] fp32 tables (positions 0..S-1).  sign=+1 forward, -1 backward.
+ * Row r sits at position pos[r] (int32 [rows], packed layout) or r % S when pos == NULL. */
+int vlb_rope_inplace(void* x, int ld, const float* cos_t, const float* sin_t, int rows, int S, int heads, int D,
+                     int sign, const int* pos, void* stream);
 /* MistralMLP gate: out[r, j] = silu(gu[r, j]) * gu[r, ff + j]   (gu = [gate | up], row stride 2*ff). */
 int vlb_swiglu_fwd(const void* gu, void* out, int rows, int ff, void* stream);
 /* dgu from dout, recomputing silu from gu. */
@@ -146,10 +152,13 @@ int vlb_im2col3d_k2s2p1(const void* x, void* cols, int B, int T, int H, int W, i
  */
 /* ids: [B,L] int64 with one video_id per row. embeds out [B, L-1+Nv, D]; key_mask out [B, L-1+Nv] bytes
  * (ids != 0, left-extended with ones).  Returns VLB_ERR_INVALID via err_flag[0] != 0 if a row lacks
- * exactly one video token (flag is device memory, checked by the caller lazily). */
+ * exactly one video token (flag is device memory, checked by the caller lazily).
+ * Packed output: with cu_rows != NULL (int32 [B+1]) only the first cu_rows[b+1]-cu_rows[b] tokens of
+ * clip b are emitted, at rows cu_rows[b].. of embeds / key_mask; row_pos (int32 [rows], optional)
+ * receives each emitted row's position in its clip (the rotary position). */
 int vlb_splice_embed(const int64_t* ids, const void* embed_w, const void* video_tokens, void* embeds,
                      uint8_t* key_mask, int* err_flag, int B, int L, int Nv, int D, int64_t video_id, int vocab,
-                     void* stream);
+                     const int* cu_rows, int* row_pos, void* stream);
 /* wmask[b, :] = [left zeros][vis_w[b,f] x tokens_per_frame][2+inst zeros][lang_w[b,:dialog]][4+pad zeros]
  * padvals int64 [B,3] = (pad_len, inst_len, dialog_len); vis_w f64 [B,F]; lang_w f64 [B,Lw]; out f32 [B,S].
  * round_bf16 != 0 rounds every weight to bf16 first, as the reference does (.to(self.config.dtype), :190-194). */
@@ -174,7 +183,11 @@ int64_t vlb_head_ws_floats(int B, int S, int E, int V);
 int vlb_head_fwd(const void* hidden, const float* wmask, const void* ln1_w, const void* ln1_b, const void* ln2_w,
                  const void* ln2_b, const void* ridge_w, const void* ridge_b, const float* y, const float* keep_scale,
                  float* ws, float* stats, float* pooled_raw, float* sumw, float* zhat, float* ln2_rstd, void* z,
-                 float* pred, float* loss_terms, int B, int S, int E, int V, float eps, float l2_lambda, void* stream);
+                 float* pred, float* loss_terms, int B, int S, int E, int V, float eps, float l2_lambda, const int* cu_rows,
+                 void* stream);
+/* Both head entry points accept packed hidden rows: cu_rows != NULL (int32 [B+1]) means clip b's
+ * hidden/dhidden rows are [cu_rows[b], cu_rows[b+1]); wmask and stats stay dense [B,S].  total_rows =
+ * cu_rows[B] on the host. */
 /* Gradients of loss wrt head parameters (fp32 outputs, overwritten) and, when dhidden != NULL, wrt
  * hidden (bf16 [B,S,E]).  loss_scale multiplies the mse term's gradient (1/world under data
  * parallelism); l2_scale the ridge penalty's.  dz_ws, dpooled_ws: [B,E] fp32 scratch. */
@@ -183,7 +196,7 @@ int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, cons
                  const float* sumw, const float* zhat, const float* ln2_rstd, const void* z, const float* pred,
                  float* d_ridge_w, float* d_ridge_b, float* d_ln2_w, float* d_ln2_b, float* d_ln1_w, float* d_ln1_b,
                  float* ws, float* dz_ws, float* dpooled_ws, void* dhidden, int B, int S, int E, int V, float eps,
-                 float l2_lambda, float loss_scale, float l2_scale, void* stream);
+                 float l2_lambda, float loss_scale, float l2_scale, const int* cu_rows, int total_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LoRA adapters (peft LoraConfig(r, lora_alpha, lora_dropout) + get_peft_model, litmodule :113-120):

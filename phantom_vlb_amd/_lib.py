@@ -26,12 +26,12 @@ SIGNATURES = {
     "vlb_gemm_bf16": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P],
     "vlb_gemm_kernel_choice": [I, I, I, I],
     "vlb_transpose_bf16": [P, P, I, I, P],
-    "vlb_attention_fwd": [P, I, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
-    "vlb_attention_bwd": [P, I, P, I, P, I, P, I, P, I, P, P, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P],
+    "vlb_attention_fwd": [P, I, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P, P],
+    "vlb_attention_bwd": [P, I, P, I, P, I, P, I, P, I, P, P, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P, I, P],
     "vlb_rmsnorm_fwd": [P, P, P, I, I, F, P],
     "vlb_rmsnorm_bwd": [P, P, P, P, P, I, I, F, P],
     "vlb_layernorm_fwd": [P, P, P, P, P, I, I, F, I, P],
-    "vlb_rope_inplace": [P, I, P, P, I, I, I, I, I, P],
+    "vlb_rope_inplace": [P, I, P, P, I, I, I, I, I, P, P],
     "vlb_swiglu_fwd": [P, P, I, I, P],
     "vlb_swiglu_bwd": [P, P, P, I, I, P],
     "vlb_add_bf16": [P, P, P, L, P],
@@ -42,12 +42,12 @@ SIGNATURES = {
     "vlb_se_pool": [P, P, I, I, I, P],
     "vlb_se_scale": [P, P, P, I, I, I, P],
     "vlb_im2col3d_k2s2p1": [P, P, I, I, I, I, I, P],
-    "vlb_splice_embed": [P, P, P, P, P, P, I, I, I, I, L, I, P],
+    "vlb_splice_embed": [P, P, P, P, P, P, I, I, I, I, L, I, P, P, P],
     "vlb_weight_mask": [P, P, P, P, I, I, I, I, I, I, P],
     "vlb_head_partial_rows": [I],
     "vlb_head_ws_floats": [I, I, I, I],
-    "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P],
-    "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P],
+    "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P, P],
+    "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P, I, P],
     "vlb_wgrad_splits": [I],
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
     "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],

@@ -245,14 +245,15 @@ class Backbone:
         return ops.gemm(x, w.ro2[0], bias=w.ro2[1])
 
     # ---------------- a7: one Mistral decoder layer (modeling_mistral.py:202-240)
-    def decoder_layer(self, x, lw, key_mask, B, S, save=None):
+    def decoder_layer(self, x, lw, key_mask, B, S, save=None, layout=None):
         g = self.g
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         h = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
         qkv = ops.gemm(h, lw["wqkv"])
-        ops.rope_(qkv, self.w.rope_cos, self.w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim)
+        ops.rope_(qkv, self.w.rope_cos, self.w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim,
+                  pos=None if layout is None else layout.pos)
         a = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads, g.head_dim,
-                              True, g.head_dim ** -0.5, key_mask=key_mask)
+                              True, g.head_dim ** -0.5, key_mask=key_mask, layout=layout)
         x = ops.gemm(a, lw["wo"], residual=x)
         h = ops.rmsnorm(x, lw["post_norm"], g.rms_eps)
         if lw.get("wgu_il") is not None:
@@ -261,9 +262,28 @@ class Backbone:
             h = ops.swiglu(ops.gemm(h, lw["wgu"]))
         return ops.gemm(h, lw["wdown"], residual=x)
 
-    def splice(self, ids, video_tokens):
+    def splice(self, ids, video_tokens, layout=None):
         g = self.g
-        return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag)
+        return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag, layout)
+
+    def row_layout(self, ids_host=None, padvals=None):
+        """Packed RowLayout for a batch whose ids (and optionally padvals) are still on the HOST, so the
+        clip lengths cost no device sync: len[b] = (last non-pad id) + Nv, i.e. everything the reference's
+        attention_mask (ids != 0, litmodule :271) keeps up to the right-padded tail.  Tokens past len[b]
+        are attended by nobody and carry zero HRF weight, so dropping their rows changes no result.
+        Returns None (dense layout) when the ids already live on the device."""
+        g = self.g
+        if ids_host is None or ids_host.device.type != "cpu":
+            return None
+        B, L = ids_host.shape
+        S = L - 1 + g.vis_tokens
+        nz = ids_host != 0
+        last = L - 1 - torch.flip(nz, dims=[1]).to(torch.int8).argmax(dim=1)        # index of the last non-pad id
+        lens = (last + g.vis_tokens).clamp(max=S)                                    # + (Nv - 1) + 1
+        lens = torch.where(nz.any(dim=1), lens, torch.full_like(lens, S))
+        if padvals is not None:               # never drop a row the weight mask could still weight
+            lens = torch.maximum(lens, S - padvals[:, 0].to(lens.dtype).cpu().clamp(min=0))
+        return ops.RowLayout(B, S, lens.tolist(), device=self.w.dev)
 
     # ---------------- fsdp.yaml-equivalent sharding of the frozen decoder weights (opt-in)
     def enable_sharding(self, group=None):
@@ -293,23 +313,24 @@ class Backbone:
         store.prefetch(i + direction)
         return {**lw, **full}
 
-    def decoder(self, x, key_mask, B, S, layer_outputs=None):
+    def decoder(self, x, key_mask, B, S, layer_outputs=None, layout=None):
         for i in range(len(self.w.layers)):
-            x = self.decoder_layer(x, self.layer_weights(i), key_mask, B, S)
+            x = self.decoder_layer(x, self.layer_weights(i), key_mask, B, S, layout=layout)
             if layer_outputs is not None:
                 layer_outputs.append(x)
         return ops.rmsnorm(x, self.w.final_norm, self.g.rms_eps)
 
-    def forward(self, vision_f32, ids, stages=None):
-        """vision fp32 [B,T,3,H,W], ids int64 [B,L] -> hidden bf16 [B*S, dim], key_mask uint8 [B,S]."""
+    def forward(self, vision_f32, ids, stages=None, layout=None):
+        """vision fp32 [B,T,3,H,W], ids int64 [B,L] -> hidden bf16 [rows, dim], key_mask uint8.
+        rows = B*S (mask [B,S]) or, with a packed ``layout``, the clips' unpadded tokens (mask [rows])."""
         g = self.g
         B = vision_f32.shape[0]
         pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
         feats = self.vision_tower(pix)
         vid = self.connector(feats, B)
-        emb, key_mask = self.splice(ids, vid)
+        emb, key_mask = self.splice(ids, vid, layout)
         louts = [] if stages is not None else None
-        hidden = self.decoder(emb, key_mask, B, g.max_len, louts)
+        hidden = self.decoder(emb, key_mask, B, g.max_len, louts, layout)
         if stages is not None:
             stages.update(vit_tokens=feats, video_tokens=vid, inputs_embeds=emb, key_mask=key_mask,
                           layer_outputs=louts, hidden=hidden)

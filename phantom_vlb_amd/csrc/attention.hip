@@ -45,6 +45,7 @@ __device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
 struct AttnArgs {
   const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
   const uint8_t* mask;
+  const int* cu;           // packed rows: clip b = rows [cu[b], cu[b+1]); NULL = dense b*S
   int ldq, ldk, ldv, ldo;
   int B, S, Hq, Hkv;
   float scale;
@@ -73,14 +74,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int qb = CAUSAL ? (nqb - 1 - blockIdx.x) : blockIdx.x;   // heavy (late) causal blocks first
   const int hq = blockIdx.y, b = blockIdx.z;
   const int hkv = hq / (p.Hq / p.Hkv);
+  const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;                 // tokens of this clip
+  const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;            // its first row
+  if (qb * QB >= Sb) return;                                          // whole workgroup past the clip's end
   const int q0 = qb * QB + wave * QW;    // first query row of this wave
   const int ql = lane & 31, h = lane >> 5;
 
   // ---- Q fragments (B operand): lane holds Q[q0+ql][16ks + 8h + j]
   bf16x8 qf[KS];
   {
-    const int qr = min(q0 + ql, p.S - 1);
-    const bf16* qp = p.q + ((int64_t)b * p.S + qr) * p.ldq + hq * D + 8 * h;
+    const int qr = min(q0 + ql, Sb - 1);
+    const bf16* qp = p.q + (row0 + qr) * p.ldq + hq * D + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
@@ -94,11 +98,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const float c2 = p.scale * 1.44269504088896341f;
 
   // number of KV tiles this workgroup needs
-  const int q_hi = min(qb * QB + QB, p.S) - 1;
-  const int ntiles = CAUSAL ? (q_hi / KV + 1) : (p.S + KV - 1) / KV;
+  const int q_hi = min(qb * QB + QB, Sb) - 1;
+  const int ntiles = CAUSAL ? (q_hi / KV + 1) : (Sb + KV - 1) / KV;
 
-  const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
-  const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
+  const bf16* kbase = p.k + row0 * p.ldk + hkv * D;
+  const bf16* vbase = p.v + row0 * p.ldv + hkv * D;
 
   // ---- K/V staging by LDS-DMA: wave-instruction i of wave w fills LDS bytes [(4i+w)*1024, +1024) of
   // the tile; the swizzle is applied on the per-lane SOURCE chunk, the LDS image stays lane-linear.
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
       const int r = (4 * i + wave) * RPI + sr;
-      const int key = min(t * KV + r, p.S - 1);   // clamp: rows past the end are masked, V stays finite
+      const int key = min(t * KV + r, Sb - 1);   // clamp: rows past the end are masked, V stays finite
       glds16(kbase + (int64_t)key * p.ldk + slot_k<D>(r, sp) * 8, kb + (4 * i + wave) * 1024);
       glds16(vbase + (int64_t)key * p.ldv + slot_v<D>(r, sp) * 8, vb + (4 * i + wave) * 1024);
     }
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       unsigned long long kvalid;
       {
         const int key = key0 + lane;
-        bool ok = key < p.S;
-        if (ok && p.mask) ok = p.mask[(int64_t)b * p.S + key] != 0;
+        bool ok = key < Sb;
+        if (ok && p.mask) ok = p.mask[row0 + key] != 0;
         kvalid = __ballot(ok);
       }
       const bool diag = CAUSAL && (key0 + KV - 1 > q0);
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
   const int qrow = q0 + ql;
-  if (qrow < p.S) {
-    bf16* op = p.o + ((int64_t)b * p.S + qrow) * p.ldo + hq * D;
+  if (qrow < Sb) {
+    bf16* op = p.o + (row0 + qrow) * p.ldo + hq * D;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -277,13 +281,13 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 
 extern "C" int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
                                  int ldo, float* lse, const uint8_t* key_mask, int B, int S, int Hq, int Hkv, int D,
-                                 int causal, float scale, void* stream) {
+                                 int causal, float scale, const int* cu_rows, void* stream) {
   VLB_REQUIRE(q && k && v && out, "attention_fwd: null operand");
   VLB_REQUIRE(D == 64 || D == 128, "attention_fwd: head dim %d not in {64,128}", D);
   VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_fwd: bad shape B=%d S=%d Hq=%d Hkv=%d", B, S, Hq, Hkv);
   VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention_fwd: strides must keep 16-byte alignment");
   VLB_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0) && ((uintptr_t)out % 8 == 0), "attention_fwd: misaligned pointer");
-  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, key_mask, ldq, ldk, ldv, ldo, B, S, Hq, Hkv, scale};
+  AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, key_mask, cu_rows, ldq, ldk, ldv, ldo, B, S, Hq, Hkv, scale};
   hipStream_t s = as_stream(stream);
   if (D == 128) return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
   return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
@@ -307,7 +311,7 @@ constexpr int BQ = 32;         // queries per inner block
 
 struct AttnBwdArgs {
   const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
-  const float* lse; const float* delta; const uint8_t* mask;
+  const float* lse; const float* delta; const uint8_t* mask; const int* cu;
   bf16* dk; bf16* dv; float* dq_acc;
   int ldq, ldk, ldv, lddo, lddk, lddv;
   int B, S, Hq, Hkv;
@@ -316,10 +320,12 @@ struct AttnBwdArgs {
 
 __device__ __forceinline__ int sw2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-// delta[b,h,s] = sum_d dout*out ; one 16-lane group per (token, head)
+// delta[b,h,s] = sum_d dout*out ; one 16-lane group per (row, head).  Packed rows are mapped back to
+// (clip, position) through cu.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, int ldo, const bf16* __restrict__ d_o,
-                                                         int lddo, float* __restrict__ delta, int S, int Hq, int64_t total) {
-  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (token, head) index
+                                                         int lddo, float* __restrict__ delta, int S, int Hq, int B,
+                                                         const int* __restrict__ cu, int64_t total) {
+  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head) index
   const int c = threadIdx.x & 15;
   float s = 0.f;
   if (gid < total) {
@@ -333,7 +339,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
   for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (gid < total && c == 0) {
     const int h = gid % Hq; const int64_t tok = gid / Hq;
-    const int64_t b = tok / S; const int sidx = tok % S;
+    int64_t b = tok / S; int sidx = tok % S;
+    if (cu) {
+      int bb = 0;
+      while (bb + 1 < B && tok >= cu[bb + 1]) ++bb;
+      b = bb; sidx = (int)(tok - cu[bb]);
+    }
     delta[(b * Hq + h) * S + sidx] = s;
   }
 }
@@ -360,6 +371,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   char* gsm = smem + G_BASE + grp * G_BYTES;
   const int kb = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
   const int k0 = kb * BK_KEYS;
+  const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
+  const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
+  if (k0 >= Sb) return;                           // no keys of this clip in the block (uniform: before any barrier)
   const int gsz = p.Hq / p.Hkv;
   const int h_lo = grp == 0 ? 0 : (gsz + 1) / 2;                   // this group's q-heads inside the GQA group
   const int h_n = grp == 0 ? (gsz + 1) / 2 : gsz / 2;
@@ -367,16 +381,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int sr = lane >> 4, sp = lane & 15;
 
-  const bf16* kbase = p.k + (int64_t)b * p.S * p.ldk + hkv * D;
-  const bf16* vbase = p.v + (int64_t)b * p.S * p.ldv + hkv * D;
+  const bf16* kbase = p.k + row0 * p.ldk + hkv * D;
+  const bf16* vbase = p.v + row0 * p.ldv + hkv * D;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = 8 * i + wave, r = piece * 4 + sr;
-    const int key = min(k0 + r, p.S - 1);
+    const int key = min(k0 + r, Sb - 1);
     glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, smem + K_OFF + piece * 1024);
     glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
   }
-  const int nqb = (p.S + BQ - 1) / BQ;
+  const int nqb = (Sb + BQ - 1) / BQ;
   const int qb0 = CAUSAL ? (k0 / BQ) : 0;
   const int nq = nqb - qb0;
   const int my_total = nq * h_n;                                   // items of this group
@@ -384,18 +398,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
 
   auto stage_q = [&](int buf, int item) {
     const int hq = hkv * gsz + h_lo + item / nq, qb = qb0 + item % nq;
-    const bf16* qbase = p.q + (int64_t)b * p.S * p.ldq + hq * D;
-    const bf16* dobase = p.dout + (int64_t)b * p.S * p.lddo + hq * D;
+    const bf16* qbase = p.q + row0 * p.ldq + hq * D;
+    const bf16* dobase = p.dout + row0 * p.lddo + hq * D;
     char* qt = gsm + G_QT + buf * 2 * QT_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int piece = 4 * i + w4, r = piece * 4 + sr;
-      const int qr = min(qb * BQ + r, p.S - 1);
+      const int qr = min(qb * BQ + r, Sb - 1);
       glds16(qbase + (int64_t)qr * p.ldq + (sp ^ sw2(r)) * 8, qt + piece * 1024);
       glds16(dobase + (int64_t)qr * p.lddo + (sp ^ sw2(r)) * 8, qt + QT_BYTES + piece * 1024);
     }
     if (w4 == 0) {
-      const int qr = min(qb * BQ + (lane & 31), p.S - 1);
+      const int qr = min(qb * BQ + (lane & 31), Sb - 1);
       const float* src = (lane < 32 ? p.lse : p.delta) + ((int64_t)b * p.Hq + hq) * p.S + qr;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(gsm + G_L + buf * 256), 4, 0, 0);
@@ -439,8 +453,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
 
   const float c2 = p.scale * 1.44269504088896341f;
   const int key = k0 + krow;
-  bool key_ok = key < p.S;
-  if (key_ok && p.mask) key_ok = p.mask[(int64_t)b * p.S + key] != 0;
+  bool key_ok = key < Sb;
+  if (key_ok && p.mask) key_ok = p.mask[row0 + key] != 0;
 
   for (int item = 0; item < total; ++item) {
     const int cur = item & 1;
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const int qrow = q0 + 8 * g + 4 * h + e;
-          bool ok = key_ok && qrow < p.S;
+          bool ok = key_ok && qrow < Sb;
           if (CAUSAL) ok = ok && (key <= qrow);
           const float pv = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
           const float ds = pv * (pacc[r] - d4[e]) * p.scale;
@@ -536,12 +550,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
           dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ta[s4][0], ta[s4][1]), join8(tk[s4][0], tk[s4][1]), dq, 0, 0, 0);
       }
       // 16 no-return fp32 atomics per wave, ALWAYS issued (rows past the end add 0 to the last valid row)
-      float* dqp = p.dq_acc + (((int64_t)b * p.S) * p.Hq + hq) * D + 32 * w4 + ql;
+      float* dqp = p.dq_acc + (row0 * p.Hq + hq) * D + 32 * w4 + ql;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = qi < p.S;
-        atomicAdd(dqp + (int64_t)min(qi, p.S - 1) * p.Hq * D, ok ? dq[r] : 0.f);
+        const bool ok = qi < Sb;
+        atomicAdd(dqp + (int64_t)min(qi, Sb - 1) * p.Hq * D, ok ? dq[r] : 0.f);
       }
       // the next tile's DMA (issued at the top of this iteration) is older than the 16 atomics:
       // vmcnt(16) retires it and leaves the atomics in flight across the barrier.
@@ -565,9 +579,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       }
   }
   __syncthreads();
-  if (grp == 0 && key < p.S) {
-    bf16* dkp = p.dk + ((int64_t)b * p.S + key) * p.lddk + hkv * D;
-    bf16* dvp = p.dv + ((int64_t)b * p.S + key) * p.lddv + hkv * D;
+  if (grp == 0 && key < Sb) {
+    bf16* dkp = p.dk + (row0 + key) * p.lddk + hkv * D;
+    bf16* dvp = p.dv + (row0 + key) * p.lddv + hkv * D;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -603,20 +617,23 @@ __global__ void dq_convert_kernel(const float* __restrict__ acc, bf16* __restric
 extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
                                  int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,
                                  int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B,
-                                 int S, int Hq, int Hkv, int D, int causal, float scale, void* stream) {
+                                 int S, int Hq, int Hkv, int D, int causal, float scale, const int* cu_rows, int total_rows,
+                                 void* stream) {
   VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta && dq_acc, "attention_bwd: null operand");
   VLB_REQUIRE(D == 128, "attention_bwd: head dim %d unsupported (only 128: the decoder)", D);
   VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
   VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&
                   lddk % 4 == 0 && lddv % 4 == 0, "attention_bwd: strides must keep vector alignment");
   hipStream_t st = as_stream(stream);
-  const int64_t th = (int64_t)B * S * Hq;
+  const int64_t rows = cu_rows ? (int64_t)total_rows : (int64_t)B * S;     // packed: sum of clip lengths
+  VLB_REQUIRE(rows > 0 && rows <= (int64_t)B * S, "attention_bwd: total_rows=%d out of range", total_rows);
+  const int64_t th = rows * Hq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((th + 15) / 16)), dim3(256), 0, st, (const bf16*)out, ldo,
-                     (const bf16*)dout, lddo, delta, S, Hq, th);
+                     (const bf16*)dout, lddo, delta, S, Hq, B, cu_rows, th);
   VLB_LAUNCH_CHECK();
   hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
   if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
-  AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask,
+  AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
                 (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
   constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
   static bool configured = false;
@@ -630,7 +647,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
   else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
   VLB_LAUNCH_CHECK();
-  const int64_t total = (int64_t)B * S * (Hq * D / 8);
+  const int64_t total = rows * (Hq * D / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dq_convert_kernel, dim3(blocks), dim3(256), 0, st, dq_acc, (bf16*)dq, lddq, Hq * D, total);
   VLB_LAUNCH_CHECK();

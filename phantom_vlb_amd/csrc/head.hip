@@ -26,9 +26,12 @@ __device__ __forceinline__ void ld8(const bf16* p, float (&v)[8]) {
 template <int NI>   // NI = ceil(E/512) chunks of 8 columns per lane
 __global__ __launch_bounds__(512) void head_pool_kernel(const bf16* __restrict__ hidden, const float* __restrict__ wmask,
                                                         float* __restrict__ partial, float* __restrict__ stats, int S,
-                                                        int E, float eps) {
+                                                        int E, float eps, const int* __restrict__ cu) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][E]
   const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  // packed hidden: clip b = rows [cu[b], cu[b+1]); wmask / stats stay dense [B,S]
+  const int Sb = cu ? cu[b + 1] - cu[b] : S;
+  const int64_t row0 = cu ? cu[b] : (int64_t)b * S;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[NI][8];
 #pragma unroll
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(512) void head_pool_kernel(const bf16* __restrict__
   // this wave's tokens: blk*32 + wave + {0,8,16,24}; rows with zero weight are skipped (wave-uniform).
   // Software pipeline: the next live row is in flight (raw bf16) while the current one is reduced.
   auto load_row = [&](int s_, bf16x8 (&dst)[NI]) {
-    const bf16* xr = hidden + ((int64_t)b * S + s_) * E;
+    const bf16* xr = hidden + (row0 + s_) * E;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane * 8 + i * 512;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(512) void head_pool_kernel(const bf16* __restrict__
 #pragma unroll
   for (int q = 0; q < POOL_ROWS / 8; ++q) {
     const int s_ = blk * POOL_ROWS + wave + 8 * q;
-    const float w_ = s_ < S ? wmask[(int64_t)b * S + s_] : 0.f;
+    const float w_ = s_ < Sb ? wmask[(int64_t)b * S + s_] : 0.f;
     if (w_ != 0.f) { live[nlive] = s_; wl[nlive] = w_; ++nlive; }
   }
   bf16x8 cur[NI], nxt[NI];
@@ -505,18 +508,24 @@ __global__ __launch_bounds__(256) void head_param_grads_kernel(const float* __re
 // ---------------------------------------------------------------- backward 4: d hidden (one wave per token)
 __global__ __launch_bounds__(256) void head_dhidden_kernel(const bf16* __restrict__ hidden, const float* __restrict__ wmask,
                                                            const float* __restrict__ stats, const float* __restrict__ draw,
-                                                           bf16* __restrict__ dh, int S, int E, int64_t rows) {
+                                                           bf16* __restrict__ dh, int S, int E, int64_t rows, int B,
+                                                           const int* __restrict__ cu) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const int64_t b = row / S;
-  const float w = wmask[row];
+  int64_t b = row / S, dense = row;             // dense = index into the [B,S] mask / stats
+  if (cu) {
+    int bb = 0;
+    while (bb + 1 < B && row >= cu[bb + 1]) ++bb;
+    b = bb; dense = b * S + (row - cu[bb]);
+  }
+  const float w = wmask[dense];
   bf16* dr = dh + row * E;
   if (w == 0.f) {
     for (int c = lane * 8; c < E; c += 512) *reinterpret_cast<bf16x8*>(dr + c) = bf16x8{};
     return;
   }
-  const float mu = stats[row * 2], rstd = stats[row * 2 + 1];
+  const float mu = stats[dense * 2], rstd = stats[dense * 2 + 1];
   const bf16* xr = hidden + row * E;
   const float* u = draw + b * E;
   float s1 = 0.f, s2 = 0.f;
@@ -548,7 +557,7 @@ int reserve_ridge_lds(int bytes) {
 
 template <int NI>
 int launch_pool(const bf16* hidden, const float* wmask, float* partial, float* stats, int B, int S, int E, float eps,
-                hipStream_t st) {
+                const int* cu, hipStream_t st) {
   const int lds = (4 * E + 8) * sizeof(float);
   static bool configured = false;
   if (!configured) {
@@ -558,7 +567,7 @@ int launch_pool(const bf16* hidden, const float* wmask, float* partial, float* s
     configured = true;
   }
   dim3 grid((S + POOL_ROWS - 1) / POOL_ROWS, B);
-  hipLaunchKernelGGL((head_pool_kernel<NI>), grid, dim3(512), lds, st, hidden, wmask, partial, stats, S, E, eps);
+  hipLaunchKernelGGL((head_pool_kernel<NI>), grid, dim3(512), lds, st, hidden, wmask, partial, stats, S, E, eps, cu);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -579,7 +588,7 @@ extern "C" int vlb_head_fwd(const void* hidden, const float* wmask, const void* 
                             const void* ln2_w, const void* ln2_b, const void* ridge_w, const void* ridge_b,
                             const float* y, const float* keep_scale, float* ws, float* stats, float* pooled_raw,
                             float* sumw, float* zhat, float* ln2_rstd, void* z, float* pred, float* loss_terms, int B,
-                            int S, int E, int V, float eps, float l2_lambda, void* stream) {
+                            int S, int E, int V, float eps, float l2_lambda, const int* cu_rows, void* stream) {
   VLB_REQUIRE(hidden && wmask && ln1_w && ln1_b && ln2_w && ln2_b && ridge_w && ridge_b && y && ws && stats &&
                   pooled_raw && sumw && zhat && ln2_rstd && z && pred && loss_terms, "head_fwd: null argument");
   VLB_REQUIRE(B > 0 && S > 0 && V > 0 && E % 8 == 0 && E > 0 && E <= 8192, "head_fwd: bad shape B=%d S=%d E=%d V=%d", B, S, E, V);
@@ -589,11 +598,11 @@ extern "C" int vlb_head_fwd(const void* hidden, const float* wmask, const void* 
   float* lpart = ws + (int64_t)B * nblk * (E + 2);
   const int ni = (E + 511) / 512;
   int rc;
-  if (ni <= 1) rc = launch_pool<1>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
-  else if (ni <= 2) rc = launch_pool<2>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
-  else if (ni <= 4) rc = launch_pool<4>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
-  else if (ni <= 8) rc = launch_pool<8>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
-  else rc = launch_pool<16>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, st);
+  if (ni <= 1) rc = launch_pool<1>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, cu_rows, st);
+  else if (ni <= 2) rc = launch_pool<2>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, cu_rows, st);
+  else if (ni <= 4) rc = launch_pool<4>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, cu_rows, st);
+  else if (ni <= 8) rc = launch_pool<8>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, cu_rows, st);
+  else rc = launch_pool<16>((const bf16*)hidden, wmask, partial, stats, B, S, E, eps, cu_rows, st);
   if (rc != VLB_OK) return rc;
   hipLaunchKernelGGL(head_reduce_kernel, dim3((E + 255) / 256, B), dim3(256), 0, st, partial, nblk, pooled_raw, sumw, E);
   VLB_LAUNCH_CHECK();
@@ -634,7 +643,7 @@ extern "C" int vlb_head_bwd(const void* hidden, const float* wmask, const void* 
                             const void* z, const float* pred, float* d_ridge_w, float* d_ridge_b, float* d_ln2_w,
                             float* d_ln2_b, float* d_ln1_w, float* d_ln1_b, float* ws, float* dz_ws, float* dpooled_ws,
                             void* dhidden, int B, int S, int E, int V, float eps, float l2_lambda, float loss_scale,
-                            float l2_scale, void* stream) {
+                            float l2_scale, const int* cu_rows, int total_rows, void* stream) {
   (void)eps;
   VLB_REQUIRE(hidden && wmask && ln1_w && ln2_w && ridge_w && y && stats && pooled_raw && sumw && zhat && ln2_rstd && z &&
                   pred && d_ridge_w && d_ridge_b && d_ln2_w && d_ln2_b && d_ln1_w && d_ln1_b && ws && dz_ws && dpooled_ws,
@@ -674,9 +683,10 @@ extern "C" int vlb_head_bwd(const void* hidden, const float* wmask, const void* 
                      pooled_raw, sumw, zhat, d_ln2_w, d_ln2_b, d_ln1_w, d_ln1_b, B, E);
   VLB_LAUNCH_CHECK();
   if (dhidden) {
-    const int64_t rows = (int64_t)B * S;
+    const int64_t rows = cu_rows ? (int64_t)total_rows : (int64_t)B * S;
+    VLB_REQUIRE(rows > 0 && rows <= (int64_t)B * S, "head_bwd: total_rows=%d out of range", total_rows);
     hipLaunchKernelGGL(head_dhidden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)hidden,
-                       wmask, stats, dpooled_ws, (bf16*)dhidden, S, E, rows);
+                       wmask, stats, dpooled_ws, (bf16*)dhidden, S, E, rows, B, cu_rows);
     VLB_LAUNCH_CHECK();
   }
   return VLB_OK;

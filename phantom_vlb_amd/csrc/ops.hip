@@ -121,13 +121,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restri
 
 // ------------------------------------------------------------------ RoPE (half rotation, in place)
 __global__ void rope_kernel(bf16* __restrict__ x, int ld, const float* __restrict__ cs, const float* __restrict__ sn,
-                            int S, int heads, int D, float sign, int64_t total) {
+                            int S, int heads, int D, float sign, const int* __restrict__ pos, int64_t total) {
   const int half = D >> 1, cpr = half >> 3;  // 8-element chunks per half head
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int ch = idx % cpr;
     const int h = (idx / cpr) % heads;
-    const int64_t tok = idx / ((int64_t)cpr * heads);   // b*S + s
-    const int s = tok % S;
+    const int64_t tok = idx / ((int64_t)cpr * heads);   // row
+    const int s = pos ? pos[tok] : (int)(tok % S);      // packed rows carry their position explicitly
     bf16* p = x + tok * ld + h * D + ch * 8;
     float a[8], b[8]; load8(p, a); load8(p + half, b);
     const float* c = cs + (int64_t)s * half + ch * 8;
@@ -325,9 +325,13 @@ __global__ void im2col3d_kernel(const bf16* __restrict__ x, bf16* __restrict__ c
 __global__ __launch_bounds__(256) void splice_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ emb,
                                                      const bf16* __restrict__ vid, bf16* __restrict__ out,
                                                      uint8_t* __restrict__ kmask, int* __restrict__ err, int L, int Nv,
-                                                     int D, int64_t video_id, int vocab) {
+                                                     int D, int64_t video_id, int vocab, const int* __restrict__ cu,
+                                                     int* __restrict__ rowpos) {
   __shared__ int s_pos, s_cnt;
-  const int b = blockIdx.y, S = L - 1 + Nv;
+  const int b = blockIdx.y, Sfull = L - 1 + Nv;
+  // packed layout: clip b owns rows [cu[b], cu[b+1]) = its first (unpadded) tokens; dense layout: b*Sfull
+  const int S = cu ? cu[b + 1] - cu[b] : Sfull;
+  const int64_t row0 = cu ? cu[b] : (int64_t)b * Sfull;
   if (threadIdx.x == 0) { s_pos = L; s_cnt = 0; }
   __syncthreads();
   for (int i = threadIdx.x; i < L; i += blockDim.x)
@@ -351,11 +355,14 @@ __global__ __launch_bounds__(256) void splice_kernel(const int64_t* __restrict__
       if (id < 0 || id >= vocab) { atomicExch(err, 2); id = 0; }
       src = emb + id * D;
     }
-    *reinterpret_cast<bf16x8*>(out + ((int64_t)b * S + s) * D + c) = *reinterpret_cast<const bf16x8*>(src + c);
+    *reinterpret_cast<bf16x8*>(out + (row0 + s) * D + c) = *reinterpret_cast<const bf16x8*>(src + c);
   }
   for (int i = threadIdx.x; i < 16; i += blockDim.x) {
     const int s = s0 + i;
-    if (s < S) kmask[(int64_t)b * S + s] = (s < Nv - 1) ? 1 : (ids[(int64_t)b * L + s - (Nv - 1)] != 0);
+    if (s < S) {
+      kmask[row0 + s] = (s < Nv - 1) ? 1 : (ids[(int64_t)b * L + s - (Nv - 1)] != 0);
+      if (rowpos) rowpos[row0 + s] = s;
+    }
   }
 }
 
@@ -451,12 +458,12 @@ extern "C" int vlb_layernorm_fwd(const void* x, const void* w, const void* b, co
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
-extern "C" int vlb_rope_inplace(void* x, int ld, const float* cos_t, const float* sin_t, int B, int S, int heads, int D,
-                                int sign, void* stream) {
-  VLB_REQUIRE(D % 16 == 0 && ld % 8 == 0 && B > 0 && S > 0 && heads > 0, "rope: bad shape D=%d ld=%d", D, ld);
-  const int64_t total = (int64_t)B * S * heads * (D / 16);
+extern "C" int vlb_rope_inplace(void* x, int ld, const float* cos_t, const float* sin_t, int rows, int S, int heads, int D,
+                                int sign, const int* pos, void* stream) {
+  VLB_REQUIRE(D % 16 == 0 && ld % 8 == 0 && rows > 0 && S > 0 && heads > 0, "rope: bad shape D=%d ld=%d", D, ld);
+  const int64_t total = (int64_t)rows * heads * (D / 16);
   hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), (bf16*)x, ld, cos_t,
-                     sin_t, S, heads, D, sign >= 0 ? 1.f : -1.f, total);
+                     sin_t, S, heads, D, sign >= 0 ? 1.f : -1.f, pos, total);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -550,12 +557,12 @@ extern "C" int vlb_im2col3d_k2s2p1(const void* x, void* cols, int B, int T, int 
 }
 extern "C" int vlb_splice_embed(const int64_t* ids, const void* embed_w, const void* video_tokens, void* embeds,
                                 uint8_t* key_mask, int* err_flag, int B, int L, int Nv, int D, int64_t video_id,
-                                int vocab, void* stream) {
+                                int vocab, const int* cu_rows, int* row_pos, void* stream) {
   VLB_REQUIRE(B > 0 && L > 0 && Nv > 0 && D % 8 == 0 && err_flag, "splice: bad shape");
   const int S = L - 1 + Nv;
   hipLaunchKernelGGL(splice_kernel, dim3((S + 15) / 16, B), dim3(256), 0, as_stream(stream), ids,
                      (const bf16*)embed_w, (const bf16*)video_tokens, (bf16*)embeds, key_mask, err_flag, L, Nv, D,
-                     video_id, vocab);
+                     video_id, vocab, cu_rows, row_pos);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

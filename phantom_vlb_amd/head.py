@@ -62,11 +62,17 @@ class BrainHead:
             self.dpooled = torch.empty(B, E, dtype=f32, device=d)
             self._cap = key
 
-    def forward(self, hidden, wmask, y, keep_scale=None):
-        """hidden bf16 [B*S,E] (or [B,S,E]), wmask f32 [B,S], y f32 [B,V] -> (pred f32 [B,V], loss_terms f32[3])."""
+    def forward(self, hidden, wmask, y, keep_scale=None, layout=None):
+        """hidden bf16 [B*S,E] (or [B,S,E]; packed rows with a packed ``layout``), wmask f32 [B,S] (always
+        dense), y f32 [B,V] -> (pred f32 [B,V], loss_terms f32[3])."""
         B, S = wmask.shape
+        packed = layout is not None and layout.packed
+        rows = layout.rows if packed else B * S
+        if hidden.numel() != rows * self.E or (packed and (layout.B, layout.S) != (B, S)):
+            raise ValueError(f"head: hidden has {hidden.numel() // self.E} rows, layout expects {rows}")
+        cu = layout.cu if packed else None
         self._buffers(B, S)
-        self._saved = (hidden, wmask, y, keep_scale)
+        self._saved = (hidden, wmask, y, keep_scale, cu, rows)
         c = self.compute
         check(lib.vlb_head_fwd(hidden.data_ptr(), wmask.data_ptr(), c["layer_norm1.weight"].data_ptr(),
                                c["layer_norm1.bias"].data_ptr(), c["layer_norm2.weight"].data_ptr(),
@@ -75,16 +81,17 @@ class BrainHead:
                                None if keep_scale is None else keep_scale.data_ptr(), self.ws.data_ptr(),
                                self.stats.data_ptr(), self.pooled_raw.data_ptr(), self.sumw.data_ptr(),
                                self.zhat.data_ptr(), self.ln2_rstd.data_ptr(), self.z.data_ptr(), self.pred.data_ptr(),
-                               self.loss_terms.data_ptr(), B, S, self.E, self.V, self.eps, self.l2_lambda, _stream()),
+                               self.loss_terms.data_ptr(), B, S, self.E, self.V, self.eps, self.l2_lambda,
+                               None if cu is None else cu.data_ptr(), _stream()),
               "vlb_head_fwd")
         return self.pred, self.loss_terms
 
     def backward(self, need_dhidden: bool, loss_scale: float = 1.0, l2_scale: float = 1.0):
         """Fills self.grads (fp32, overwritten) and returns d loss / d hidden (bf16) or None."""
-        hidden, wmask, y, keep_scale = self._saved
+        hidden, wmask, y, keep_scale, cu, rows = self._saved
         B, S = wmask.shape
         c, gr = self.compute, self.grads
-        dh = torch.empty(B * S, self.E, dtype=BF16, device=self.dev) if need_dhidden else None
+        dh = torch.empty(rows, self.E, dtype=BF16, device=self.dev) if need_dhidden else None
         check(lib.vlb_head_bwd(hidden.data_ptr(), wmask.data_ptr(), c["layer_norm1.weight"].data_ptr(),
                                c["layer_norm2.weight"].data_ptr(), c["ridge_layer.linear.weight"].data_ptr(),
                                y.data_ptr(), None if keep_scale is None else keep_scale.data_ptr(),
@@ -95,5 +102,6 @@ class BrainHead:
                                gr["layer_norm1.weight"].data_ptr(), gr["layer_norm1.bias"].data_ptr(),
                                self.ws.data_ptr(), self.dz.data_ptr(), self.dpooled.data_ptr(),
                                None if dh is None else dh.data_ptr(), B, S, self.E, self.V, self.eps, self.l2_lambda,
-                               float(loss_scale), float(l2_scale), _stream()), "vlb_head_bwd")
+                               float(loss_scale), float(l2_scale), None if cu is None else cu.data_ptr(), rows,
+                               _stream()), "vlb_head_bwd")
         return dh

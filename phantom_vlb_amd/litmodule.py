@@ -72,6 +72,7 @@ class VLBLitModuleConfig:
     geometry: str = "7b"            # "7b" | "mini"
     init_seed: int = 1234
     gradient_clip_val: float = 1.0  # the Trainer's gradient_clip_val, applied inside the fused AdamW
+    pack_tokens: bool = True        # drop each clip's padded tail rows (flash-attn varlen equivalent)
 
     def __post_init__(self):
         self.dtype = torch.bfloat16      # reference :155
@@ -99,6 +100,7 @@ class VLBLitModule(_Base):
         self._step = 0
         self.world_size = 1
         self.rank = 0
+        self.pack_tokens = bool(getattr(config, "pack_tokens", True))
 
     @property
     def device(self):
@@ -164,25 +166,28 @@ class VLBLitModule(_Base):
             x_video = torch.stack([v[0] if isinstance(v, (list, tuple)) else v for v in x_video])
         return x_video.to(self.device, torch.float32).contiguous()
 
-    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None):
+    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None, layout=None):
         """reference :229-256 -> (regression_output fp32 [B,V], l2_reg).  attention_mask is re-derived
-        on the device from the ids (ids != 0), exactly what the reference passes in (:271)."""
+        on the device from the ids (ids != 0), exactly what the reference passes in (:271).
+        ``layout``: packed RowLayout from ``backbone.row_layout`` (rows without padded tails)."""
         vis = self._vision_tensor(x_video)
         ids = x_lang.to(self.device, torch.int64).contiguous()
         B = ids.shape[0]
         if self.lora is not None and self.training:
-            hidden, key_mask = self.lora.forward(self.backbone, vis, ids)
+            hidden, key_mask = self.lora.forward(self.backbone, vis, ids, layout)
         else:
-            hidden, key_mask = self.backbone.forward(vis, ids)
+            hidden, key_mask = self.backbone.forward(vis, ids, layout=layout)
         if y is None:
             y = torch.zeros(B, self.config.num_target, dtype=torch.float32, device=self.device)
-        pred, terms = self.head.forward(hidden, weight_mask, y, keep_scale)
+        pred, terms = self.head.forward(hidden, weight_mask, y, keep_scale, layout)
         self._loss_terms = terms
         return pred, terms[1]
 
     def _common_step(self, batch, train: bool):
         cfg, g = self.config, self.geometry
         dev = self.device
+        # unpadded (packed) rows, like the reference's flash-attn path; needs the ids on the host (no sync)
+        layout = self.backbone.row_layout(batch["language"], batch["padvals"]) if self.pack_tokens else None
         x_lang = batch["language"].to(dev).long()
         wm = self.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], x_lang.shape[1],
                                    self.nnmodule.config.tokenizer_model_max_length)
@@ -190,7 +195,7 @@ class VLBLitModule(_Base):
         keep = None
         if train and cfg.dropout_rate > 0:
             keep = (torch.rand(x_lang.shape[0], g.dim, device=dev) >= cfg.dropout_rate).float() / (1.0 - cfg.dropout_rate)
-        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep)
+        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout)
         return pred, y, self._loss_terms
 
     def training_step(self, batch):

@@ -161,11 +161,12 @@ class LoraState:
         return x or 1
 
     def _workspace(self, M):
-        if self._ws is None or self._ws["M"] != M:
+        if self._ws is None or self._ws["cap"] < M:          # grow-only: packed batches change M every step
             g, d = self.g, self.dev
             kmax = max(g.ff, g.dim, g.heads * g.head_dim)
-            self._ws = dict(M=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
-                            u=torch.zeros(M, PAD, dtype=BF16, device=d))
+            self._ws = dict(cap=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
+                            u_full=torch.zeros(M, PAD, dtype=BF16, device=d))
+        self._ws["u"] = self._ws["u_full"][:M]
         return self._ws
 
     # ------------------------------------------------------------------ forward with saved activations
@@ -174,14 +175,16 @@ class LoraState:
         lora_down(x, blk["A"], blk["R"], self.scale, self.p, seeds, t)
         return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
 
-    def forward(self, backbone, vision_f32, ids):
-        """Training forward of the whole backbone; decoder activations are kept for backward."""
+    def forward(self, backbone, vision_f32, ids, layout=None):
+        """Training forward of the whole backbone; decoder activations are kept for backward.
+        ``layout``: packed RowLayout (rows without the clips' padded tails) or None for dense [B,S]."""
         g, w = self.g, self.w
         B = vision_f32.shape[0]
         S = g.max_len
+        pos = None if layout is None else layout.pos
         pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
         vid = backbone.connector(backbone.vision_tower(pix), B)          # frozen: no activations kept
-        x, key_mask = backbone.splice(ids, vid)
+        x, key_mask = backbone.splice(ids, vid, layout)
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         self.saved = []
         self.step += 1
@@ -190,9 +193,10 @@ class LoraState:
             sd = [self._seed(li, k) for k in range(7)]
             h1 = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
             qkv, t_qkv = self._adapted(h1, lw["wqkv"], lay["qkv"], sd[0:3])
-            ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim)
+            ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
             a, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads,
-                                       g.head_dim, True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True)
+                                       g.head_dim, True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True,
+                                       layout=layout)
             x2, t_o = self._adapted(a, lw["wo"], lay["o"], sd[3:4], residual=x)
             h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
             gu, t_gu = self._adapted(h2, lw["wgu"], lay["gu"], sd[4:6])
@@ -201,7 +205,7 @@ class LoraState:
             self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh, t_qkv=t_qkv, t_o=t_o,
                                    t_gu=t_gu, t_d=t_d, seeds=sd))
             x = x3
-        self.x_last, self.key_mask, self.B = x, key_mask, B
+        self.x_last, self.key_mask, self.B, self.layout = x, key_mask, B, layout
         return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
 
     # ------------------------------------------------------------------ backward
@@ -235,7 +239,9 @@ class LoraState:
         g, w = self.g, self.w
         B, S = self.B, g.max_len
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
-        M = B * S
+        layout = self.layout
+        pos = None if layout is None else layout.pos
+        M = self.x_last.shape[0]
         dx = ops.rmsnorm_bwd(self.x_last, w.final_norm, dhidden, g.rms_eps)
         delta = torch.empty(B, g.heads, S, dtype=torch.float32, device=self.dev)
         dq_acc = torch.empty(M, qd, dtype=torch.float32, device=self.dev)
@@ -248,15 +254,9 @@ class LoraState:
             dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
             d_a = self._group_backward(li, "o", dx2, sv["a"], sv["t_o"], sd[3:4], lw["wo_t"], True)
             qkv = sv["qkv"]
-            dqkv = torch.empty_like(qkv)
-            check(lib.vlb_attention_bwd(qkv.data_ptr(), qkv.stride(0), qkv[:, qd:].data_ptr(), qkv.stride(0),
-                                        qkv[:, qd + kd:].data_ptr(), qkv.stride(0), sv["a"].data_ptr(), sv["a"].stride(0),
-                                        d_a.data_ptr(), d_a.stride(0), sv["lse"].data_ptr(), self.key_mask.data_ptr(),
-                                        dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
-                                        dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), dq_acc.data_ptr(),
-                                        B, S, g.heads, g.kv_heads, g.head_dim, 1, g.head_dim ** -0.5, _stream()),
-                  "vlb_attention_bwd")
-            ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1)
+            dqkv = ops.attention_bwd(qkv, qd, kd, sv["a"], d_a, sv["lse"], self.key_mask, B, S, g.heads, g.kv_heads,
+                                     g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta, dq_acc=dq_acc)
+            ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
             need_dx = li > 0                # embeddings / connector are frozen: nothing upstream of layer 0 trains
             d_h1 = self._group_backward(li, "qkv", dqkv, sv["h1"], sv["t_qkv"], sd[0:3], lw["wqkv_t"], need_dx)
             if need_dx:

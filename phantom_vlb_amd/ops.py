@@ -97,16 +97,82 @@ def transpose(x):
     return out
 
 
-def attention_fwd(q, k, v, B, S, Hq, Hkv, D, causal, scale, key_mask=None, need_lse=False, out=None):
-    """q/k/v: 2-D views [B*S, H*D] (row stride = token stride, may be slices of a packed qkv buffer)."""
+class RowLayout:
+    """How the token rows of B clips are laid out: dense ``[B, S]`` (``lens=None``) or packed - clip b
+    owns rows ``cu[b]..cu[b+1]`` and its padded tail is simply not there (the flash-attn varlen layout
+    the reference's decoder runs on, modeling_mistral.py ``_upad_input``).  ``lens`` are HOST ints, so
+    building a layout never reads device memory."""
+
+    def __init__(self, B, S, lens=None, device=None):
+        self.B, self.S = int(B), int(S)
+        if lens is None:
+            self.cu = self.pos = self.lens = None
+            self.rows, self.smax = self.B * self.S, self.S
+            return
+        lens = [int(x) for x in lens]
+        if len(lens) != self.B or min(lens) < 1 or max(lens) > self.S:
+            raise ValueError(f"RowLayout: lens {lens} do not fit B={B}, S={S}")
+        cu = [0]
+        for n in lens:
+            cu.append(cu[-1] + n)
+        self.lens, self.rows, self.smax = lens, cu[-1], max(lens)
+        self.cu = torch.tensor(cu, dtype=torch.int32).to(device, non_blocking=True)
+        self.pos = torch.empty(self.rows, dtype=torch.int32, device=device)      # filled by splice_embed
+
+    @property
+    def packed(self):
+        return self.cu is not None
+
+    def unpack(self, x, fill=0.0):
+        """[rows, C] -> dense [B, S, C] (padding rows = fill); test / inspection helper."""
+        if not self.packed:
+            return x.view(self.B, self.S, -1)
+        out = torch.full((self.B, self.S, x.shape[1]), fill, dtype=x.dtype, device=x.device)
+        o = 0
+        for b, n in enumerate(self.lens):
+            out[b, :n] = x[o:o + n]
+            o += n
+        return out
+
+
+def attention_fwd(q, k, v, B, S, Hq, Hkv, D, causal, scale, key_mask=None, need_lse=False, out=None, layout=None):
+    """q/k/v: 2-D views [rows, H*D] (row stride = token stride, may be slices of a packed qkv buffer).
+    ``layout`` (a packed RowLayout) overrides B/S: rows follow layout.cu, lse is [B,Hq,layout.smax]."""
     _dev(q)
+    cu, rows = None, B * S
+    if layout is not None and layout.packed:
+        B, S, cu, rows = layout.B, layout.smax, layout.cu, layout.rows
+    assert q.shape[0] == rows, f"attention_fwd: {q.shape[0]} rows, layout has {rows}"
     if out is None:
-        out = torch.empty(B * S, Hq * D, dtype=BF16, device=q.device)
+        out = torch.empty(rows, Hq * D, dtype=BF16, device=q.device)
     lse = torch.empty(B, Hq, S, dtype=torch.float32, device=q.device) if need_lse else None
     check(lib.vlb_attention_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                 out.data_ptr(), out.stride(0), _p(lse), _p(key_mask), B, S, Hq, Hkv, D,
-                                1 if causal else 0, float(scale), _stream()), "vlb_attention_fwd")
+                                1 if causal else 0, float(scale), _p(cu), _stream()), "vlb_attention_fwd")
     return (out, lse) if need_lse else out
+
+
+def attention_bwd(qkv, qd, kd, out, dout, lse, key_mask, B, S, Hq, Hkv, D, causal, scale, layout=None, delta=None,
+                  dq_acc=None):
+    """Backward through attention_fwd on a fused [rows, qd+2*kd] qkv buffer -> dqkv of the same shape."""
+    cu, rows = None, B * S
+    if layout is not None and layout.packed:
+        B, S, cu, rows = layout.B, layout.smax, layout.cu, layout.rows
+    assert qkv.shape[0] == rows and dout.shape[0] == rows
+    if delta is None:
+        delta = torch.empty(B, Hq, S, dtype=torch.float32, device=qkv.device)
+    if dq_acc is None:
+        dq_acc = torch.empty(rows, qd, dtype=torch.float32, device=qkv.device)
+    assert delta.numel() >= B * Hq * S and dq_acc.numel() >= rows * qd
+    dqkv = torch.empty_like(qkv)
+    check(lib.vlb_attention_bwd(qkv.data_ptr(), qkv.stride(0), qkv[:, qd:].data_ptr(), qkv.stride(0),
+                                qkv[:, qd + kd:].data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0),
+                                dout.data_ptr(), dout.stride(0), lse.data_ptr(), _p(key_mask),
+                                dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
+                                dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), dq_acc.data_ptr(),
+                                B, S, Hq, Hkv, D, 1 if causal else 0, float(scale), _p(cu), rows, _stream()),
+          "vlb_attention_bwd")
+    return dqkv
 
 
 def rmsnorm(x, w, eps, out=None):
@@ -135,10 +201,13 @@ def layernorm(x, w, b, eps, residual=None, act=ACT_NONE, out=None):
     return out
 
 
-def rope_(x, cos, sin, B, S, heads, D, sign=1):
-    """In place on the first heads*D columns of the 2-D view x [B*S, >=heads*D]."""
-    check(lib.vlb_rope_inplace(_dev(x).data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(), B, S, heads, D, sign,
-                               _stream()), "vlb_rope_inplace")
+def rope_(x, cos, sin, B, S, heads, D, sign=1, pos=None):
+    """In place on the first heads*D columns of the 2-D view x [rows, >=heads*D]; row r is at position
+    pos[r] (packed layout) or r % S."""
+    rows = B * S if pos is None else pos.shape[0]
+    assert x.shape[0] == rows and cos.shape[0] >= S
+    check(lib.vlb_rope_inplace(_dev(x).data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(), rows, S, heads, D, sign,
+                               _p(pos), _stream()), "vlb_rope_inplace")
     return x
 
 
@@ -212,15 +281,22 @@ def im2col3d(x, B, T, H, W, C):
     return out
 
 
-def splice_embed(ids, embed_w, video_tokens, Nv, video_id, err_flag):
+def splice_embed(ids, embed_w, video_tokens, Nv, video_id, err_flag, layout=None):
+    """-> (embeds [rows, D], key_mask).  Dense: rows = B*S, mask [B,S].  With a packed ``layout`` only
+    each clip's first lens[b] tokens are emitted (mask [rows]) and layout.pos receives their positions."""
     B, L = ids.shape
     D = embed_w.shape[1]
     S = L - 1 + Nv
     assert ids.dtype == torch.int64 and ids.is_contiguous()
-    out = torch.empty(B * S, D, dtype=BF16, device=ids.device)
-    mask = torch.empty(B, S, dtype=torch.uint8, device=ids.device)
+    packed = layout is not None and layout.packed
+    if packed:
+        assert layout.B == B and layout.S == S
+    rows = layout.rows if packed else B * S
+    out = torch.empty(rows, D, dtype=BF16, device=ids.device)
+    mask = torch.empty((rows,) if packed else (B, S), dtype=torch.uint8, device=ids.device)
     check(lib.vlb_splice_embed(_dev(ids).data_ptr(), embed_w.data_ptr(), video_tokens.data_ptr(), out.data_ptr(),
                                mask.data_ptr(), err_flag.data_ptr(), B, L, Nv, D, video_id, embed_w.shape[0],
+                               _p(layout.cu) if packed else None, _p(layout.pos) if packed else None,
                                _stream()), "vlb_splice_embed")
     return out, mask
 

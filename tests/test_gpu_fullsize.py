@@ -174,3 +174,34 @@ def test_step_is_deterministic(dev):
     l1 = float(m.training_step(batch)); g1 = m.flat.grad.clone()
     l2 = float(m.training_step(batch)); g2 = m.flat.grad.clone()
     assert l1 == l2 and torch.equal(g1, g2)
+
+
+def test_7b_step_packed_equals_dense(dev):
+    """BASELINE configs[1] at full size (7B frozen backbone, 2048 targets, max_len 2048, B=2): the
+    unpadded row layout gives the SAME loss and head gradients, bit for bit, as the dense layout."""
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.synthetic import synthetic_batch
+    cfg = VLBLitModuleConfig(model_path="none", freeze_backbone=True, use_lora=False, lora_r=None, lora_alpha=None,
+                             lora_dropout=None, dropout_rate=0.0, num_target=2048, l2_lambda=1e-3, lr=1e-4,
+                             betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR",
+                             last_epoch=-1, t_max=50000, geometry="7b")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VLBLitModule(cfg)
+        m.configure_model()
+    m.configure_optimizers()
+    batch = synthetic_batch(m.geometry, 2, seed=3, device=m.device)
+    batch["language"], batch["padvals"] = batch["language"].cpu(), batch["padvals"].cpu()
+    lay = m.backbone.row_layout(batch["language"], batch["padvals"])
+    assert lay.rows < 2 * m.geometry.max_len            # the synthetic clips do carry padding
+    res = {}
+    for pack in (False, True):
+        m.pack_tokens = pack
+        loss = float(m.training_step(batch))
+        res[pack] = (loss, m.flat.grad.clone(), m.head.pred.clone())
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    assert torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][1], res[False][1])
+    del m
+    torch.cuda.empty_cache()

@@ -159,16 +159,7 @@ def test_attention_bwd(dev, B, S, Hq, Hkv, causal, masked):
     dout_d = (dout.float().view(B, S, Hq, D) * valid).to(BF).view(B * S, Hq * D).to(dev)
     out, lse = ops.attention_fwd(dq_[:, :qd], dq_[:, qd:qd + kd], dq_[:, qd + kd:], B, S, Hq, Hkv, D, causal, D ** -0.5,
                                  key_mask=dmask, need_lse=True)
-    dqkv = torch.zeros_like(dq_)
-    delta = torch.empty(B, Hq, S, dtype=torch.float32, device=dev)
-    acc = torch.empty(B * S, qd, dtype=torch.float32, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    check(lib.vlb_attention_bwd(dq_.data_ptr(), dq_.stride(0), dq_[:, qd:].data_ptr(), dq_.stride(0),
-                                dq_[:, qd + kd:].data_ptr(), dq_.stride(0), out.data_ptr(), out.stride(0),
-                                dout_d.data_ptr(), dout_d.stride(0), lse.data_ptr(), None if dmask is None else dmask.data_ptr(),
-                                dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
-                                dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), acc.data_ptr(), B, S, Hq, Hkv,
-                                D, 1 if causal else 0, D ** -0.5, st), "bwd")
+    dqkv = ops.attention_bwd(dq_, qd, kd, out, dout_d, lse, dmask, B, S, Hq, Hkv, D, causal, D ** -0.5)
     got = dqkv.float().cpu()
     assert rel_err(got[:, :qd].view(B, S, Hq, D), dq_ref) < 2e-2
     assert rel_err(got[:, qd:qd + kd].view(B, S, Hkv, D), dk_ref) < 2e-2
@@ -240,7 +231,13 @@ def test_mini_lora_dropout_matches_oracle(dev):
     m.configure_optimizers()
     loss = m.training_step(batch)
     # rebuild the masks the kernels used (step counter is 1 after the first forward)
-    M = 2 * g.max_len
+    lens = m.backbone.row_layout(batch["language"], batch["padvals"]).lens   # the step ran on packed rows
+    M = sum(lens)
+
+    def dense(mask):                     # packed rows [M,K] -> [2,S,K]; padded rows never reach the loss
+        out = torch.ones(2, g.max_len, mask.shape[1])
+        out[0, :lens[0]], out[1, :lens[1]] = mask[:lens[0]], mask[lens[0]:]
+        return out
     drop = {}
     for li in range(g.layers):
         idx = 0
@@ -248,7 +245,7 @@ def test_mini_lora_dropout_matches_oracle(dev):
             for t in targets:
                 seed = m.lora._seed(li, idx)
                 K = m.lora.in_dims[t]
-                drop[f"model.layers.{li}.{t}"] = (keep_mask(seed, M, K, 0.1).float() / 0.9).view(2, g.max_len, K)
+                drop[f"model.layers.{li}.{t}"] = dense(keep_mask(seed, M, K, 0.1).float() / 0.9)
                 idx += 1
     names = O.trainable_names(p, False, True)
     pr = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
