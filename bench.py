@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
 # L2->fabric bytes of ONE gate/up GEMM launch at B=5, measured offline with rocprofv3 --pmc (separate FETCH_SIZE /
 # WRITE_SIZE passes, gfx950 2x read correction): profiles/r01_gemm_gateup_hbm_traffic.csv.  Only valid for that shape.
-GATEUP_TRAFFIC_BYTES_B5 = 3.904e9
+GATEUP_TRAFFIC_BYTES = {(10240, 28672, 4096): 3.904e9,     # dense rows (--no-pack)
+                        (9447, 28672, 4096): 4.060e9}      # packed rows of the default synthetic batch (r01_..._packed.csv)
 # algorithmic TFLOP per clip
 TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8}
 
@@ -177,8 +178,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<256,256> on gate/up projection "
                          f"[{pM}x{pK}]x[{pN}x{pK}]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": GATEUP_TRAFFIC_BYTES_B5 if (pM, pN, pK) == (10240, 28672, 4096) else None,
-                         "traffic_note": "L2->fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic.csv); algorithmic 6.12e8",
+                         "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
+                         "traffic_note": "L2->fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic*.csv); "
+                         f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)",
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":
