@@ -9,6 +9,8 @@
 // MFMA operand roles are swapped on purpose (rows of the MFMA = output COLUMNS n, columns of the
 // MFMA = output rows m): each lane then owns 4 consecutive n of one row m per 16x16 tile, so the
 // epilogue packs 4 bf16 into one 8-byte store and bias/residual are 8-byte loads.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -23,8 +25,35 @@ struct GemmArgs {
   int M, N, K, K2;
   int lda, ldw, ldc, ldr, lda2, ldw2;
   int act;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n;     // grid of PARENT tiles (BM x BN*split_n) the tile order is defined on
+  int tile0;                // first parent tile of this launch (the launch covers [tile0, tile0 + grid/split_n))
+  int split_n;              // a workgroup computes 1/split_n of a parent tile's columns (tail launches)
+  int grid;                 // workgroups of this launch (host side only)
 };
+
+// blockIdx -> (m0, n0).  XCD-aware: blocks b and b+8 share an XCD, so each XCD gets a contiguous run of the
+// launch's tiles; tiles are walked in bands of GROUP_M row-tiles so concurrently resident tiles share A/W
+// panels in that XCD's L2.  The order is defined on the full parent grid, so a GEMM can be cut into several
+// launches (full waves with 256x256 tiles + a partial last wave re-tiled 256x128) at any tile index.
+__device__ __forceinline__ void map_tile(const GemmArgs& p, int BM, int BN, int& m0, int& n0) {
+  const int nblk = gridDim.x;
+  int pid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
+    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  int sub = 0;
+  if (p.split_n > 1) { sub = pid % p.split_n; pid /= p.split_n; }
+  pid += p.tile0;
+  constexpr int GROUP_M = 4;
+  const int band = GROUP_M * p.tiles_n;
+  const int g0 = (pid / band) * GROUP_M;
+  const int gsz = min(p.tiles_m - g0, GROUP_M);
+  const int tm = g0 + (pid % band) % gsz;
+  const int tn = (pid % band) / gsz;
+  m0 = tm * BM;
+  n0 = (tn * p.split_n + sub) * BN;
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
@@ -55,21 +84,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
   constexpr int A_LD = BM / 64, B_LD = BN / 64;  // glds instructions per thread per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // ---- XCD-aware tile order: blocks b and b+8 share an XCD, give each XCD a contiguous run of
-  // tiles, walked in bands of GROUP_M row-tiles so concurrently resident tiles share A/W panels in L2.
-  const int nblk = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
-    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  constexpr int GROUP_M = 4;
-  const int band = GROUP_M * p.tiles_n;
-  const int g0 = (pid / band) * GROUP_M;
-  const int gsz = min(p.tiles_m - g0, GROUP_M);
-  const int tm = g0 + (pid % band) % gsz;
-  const int tn = (pid % band) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0, n0;
+  map_tile(p, BM, BN, m0, n0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -220,19 +236,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   constexpr int A_LD = BM / 64, B_LD = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int nblk = p.tiles_m * p.tiles_n;
-  int pid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
-    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  constexpr int GROUP_M = 4;
-  const int band = GROUP_M * p.tiles_n;
-  const int g0 = (pid / band) * GROUP_M;
-  const int gsz = min(p.tiles_m - g0, GROUP_M);
-  const int tm = g0 + (pid % band) % gsz;
-  const int tn = (pid % band) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0, n0;
+  map_tile(p, BM, BN, m0, n0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -486,7 +491,255 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   }
 }
 
-int g_variant = 1;      // 0: lock-step double buffer, 1: ping-pong wave groups (default)
+// ------------------------------------------------------------------------------------------------
+// Four-wave variant of the 256x256x64 tile: 256 threads = 2x2 waves, each wave owns a 128x128 block
+// (8x8 MFMA tiles, 256 accumulator registers - one wave per SIMD with the full 512-register budget).
+// Why: per K-tile the 8-wave kernels read (128+64)*64*2 B * 8 = 192 KB of fragments from LDS plus the
+// 64 KB LDS-DMA write = 2048 LDS cycles at 128 B/clk - exactly the 2048 MFMA cycles of the tile, so the
+// two pipes must overlap perfectly.  128x128 wave blocks read (128+128)*64*2 B * 4 = 128 KB (1536 cycles
+// with the DMA): a quarter of the LDS time becomes slack, and one barrier per K-tile replaces four.
+// Schedule of one wave (software pipelined, no partner wave to hide behind):
+//   block 1:  MFMAs of k-step 0   || ds_reads of k-step 1 fragments
+//   lgkmcnt(0), vmcnt(0) (tile t+1 landed; it was issued 1.5 tiles ago), s_barrier
+//   block 2:  MFMAs of k-step 1   || LDS-DMA of tile t+2 into the buffer just released
+//                                 || ds_reads of tile t+1's k-step 0 fragments
+// Instruction mix per 4 MFMAs (64 cycles of matrix pipe): one ds_read_b128 (+ one LDS-DMA in block 2).
+// ------------------------------------------------------------------------------------------------
+// MFMA with the accumulator tied in place in an AGPR tuple.  With all 256 AGPRs holding accumulators the
+// register allocator otherwise rotates destination tuples through copies; the asm form pins dst == srcC.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+               : "+a"(c)
+               : "v"(__builtin_bit_cast(i32x4_t, a)), "v"(__builtin_bit_cast(i32x4_t, b)));
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, TM = 128, TN = 128, MT = 8, NT = 8;
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;       // LDS-DMA instructions per thread per tile (32 rows each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int m0, n0;
+  map_tile(p, BM, BN, m0, n0);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging: instruction i of this wave fills LDS rows [i*32 + wave*8, +8) of A (i < A_LD) or W.
+  // Sources are (uniform base) + 32-bit byte offset, recomputed per instruction from two row numbers:
+  // no per-instruction pointer arrays (the 128 fragment + 256 accumulator registers leave no room).
+  // The swizzle term ((r>>1)&7) is the same for rows r and r + 32*i.
+  const int srow = (lane >> 3), sslot = lane & 7;
+  const int r0 = wave * 8 + srow;
+  const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
+  const int rowA = m0 + r0, rowW = n0 + r0;
+  const int nk1 = p.K / BK;
+  const int nk = nk1 + p.K2 / BK;
+
+  // LDS-DMA sources = uniform base (SGPR pair, advanced 128 B per K-tile) + a per-instruction 32-bit
+  // byte offset held in a VGPR: the loop issues each global_load_lds with no address arithmetic at all.
+  // The offsets are rebuilt once when the K loop crosses into the second operand pair (A2, W2).
+  uint32_t offA[A_LD], offW[B_LD];
+  const char* curA; const char* curW;
+  auto set_operands = [&](const bf16* A_, const bf16* W_, int lda_, int ldw_) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i)
+      offA[i] = ((uint32_t)min(rowA + 32 * i, p.M - 1) * (uint32_t)lda_ + (uint32_t)colb) * 2u;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) offW[j] = ((uint32_t)(rowW + 32 * j) * (uint32_t)ldw_ + (uint32_t)colb) * 2u;
+    curA = reinterpret_cast<const char*>(A_);
+    curW = reinterpret_cast<const char*>(W_);
+  };
+  auto select = [&](int kt) {           // call with consecutive kt: positions the bases on K-tile kt
+    if (kt == 0) set_operands(p.A, p.W, p.lda, p.ldw);
+    else if (kt == nk1) set_operands(p.A2, p.W2, p.lda2, p.ldw2);
+    else { curA += ROW_BYTES; curW += ROW_BYTES; }
+  };
+  auto dma = [&](int buf, int i) {     // instruction i of the selected tile (0..A_LD-1: A, then W)
+    char* base = smem + buf * STAGE + wave * 8 * ROW_BYTES;
+    if (i < A_LD) glds16(curA + offA[i], base + i * 32 * ROW_BYTES);
+    else glds16(curW + offW[i - A_LD], base + A_BYTES + (i - A_LD) * 32 * ROW_BYTES);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment offsets: tile i adds i*16 rows = i*2048 bytes (the swizzle term does not depend on i)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_off[ks] = lds_off(wm * TM + fr, ks * 4 + fq);
+    b_off[ks] = A_BYTES + lds_off(wn * TN + fr, ks * 4 + fq);
+  }
+  auto frag = [&](const char* sb, int off, int t) { return *reinterpret_cast<const bf16x8*>(sb + off + t * 16 * ROW_BYTES); };
+
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define W4_BARRIER() do { W4_FENCE(); __builtin_amdgcn_s_barrier(); W4_FENCE(); } while (0)
+
+  select(0);
+#pragma unroll
+  for (int i = 0; i < A_LD + B_LD; ++i) dma(0, i);
+  if (nk > 1) {
+    select(1);
+#pragma unroll
+    for (int i = 0; i < A_LD + B_LD; ++i) dma(1, i);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed; tile 1 may still fly
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  W4_BARRIER();
+
+  // Fragment registers: W fragments are double-buffered (wf[0], wf[1]); A fragments are refreshed IN
+  // PLACE - with the i-major MFMA order af[i] dies after groups 2i and 2i+1, so the next k-step's af[i]
+  // is loaded right behind it.  Only af[7] dies too late (it would have to be read after the barrier that
+  // releases its buffer), so it alone has a second slot (a7[2]).
+  bf16x8 wf[2][NT], af[MT - 1], a7[2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) wf[0][j] = frag(smem, b_off[0], j);
+#pragma unroll
+  for (int i = 0; i < MT - 1; ++i) af[i] = frag(smem, a_off[0], i);
+  a7[0] = frag(smem, a_off[0], MT - 1);
+  __builtin_amdgcn_s_waitcnt(0xc07f);        // so that no compiler-inserted wait lands inside the loop
+  W4_FENCE();
+
+  // one K-tile; MORE: a tile kt+1 exists (fetch its first fragments), LOAD2: tile kt+2 exists (LDS-DMA it)
+  auto tile = [&](int kt, auto more_c, auto load2_c) {
+    constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
+    const char* sb = smem + (kt & 1) * STAGE;
+    const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
+    // ---------------- block 1: MFMA(k-step 0) || reads of k-step 1
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (!(ABL & 2) || kt == 0) {
+        if (g < 8) wf[1][g] = frag(sb, b_off[1], g);
+        if (g >= 2 && (g & 1) == 0) af[g / 2 - 1] = frag(sb, a_off[1], g / 2 - 1);     // af[i] died in group 2i+1
+        if (g == 9) a7[1] = frag(sb, a_off[1], MT - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = g * 4 + q, i = t >> 3, j = t & 7;
+        mfma_tied(acc[i][j], wf[0][j], i == MT - 1 ? a7[0] : af[i]);
+      }
+      W4_FENCE();
+    }
+    // every wave is done reading buffer kt&1 (lgkmcnt) and its pieces of tile kt+1 have landed (vmcnt)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if constexpr (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!(ABL & 4)) { W4_BARRIER(); } else { W4_FENCE(); }
+    if constexpr (LOAD2) select(kt + 2);
+    // ---------------- block 2: MFMA(k-step 1) || DMA of tile kt+2 || reads of tile kt+1, k-step 0
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if constexpr (LOAD2 && !(ABL & 1)) dma(kt & 1, g);
+      if constexpr (MORE && !(ABL & 2)) {
+        if (g < 8) wf[0][g] = frag(sn, b_off[0], g);
+        if (g >= 2 && (g & 1) == 0) af[g / 2 - 1] = frag(sn, a_off[0], g / 2 - 1);
+        if (g == 9) a7[0] = frag(sn, a_off[0], MT - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = g * 4 + q, i = t >> 3, j = t & 7;
+        mfma_tied(acc[i][j], wf[1][j], i == MT - 1 ? a7[1] : af[i]);
+      }
+      W4_FENCE();
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // all of the next block's fragments are in (issued >= 2 groups ago)
+    // accumulator copies the register allocator may place on the loop's exit edges must not overtake the
+    // last (asm, hence opaque) MFMAs: XDL-write -> VALU-read needs up to 18 wait states
+    asm volatile("s_nop 15" ::: "memory");
+    W4_FENCE();
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) tile(kt, T_{}, T_{});
+  if (kt + 1 < nk) { tile(kt, T_{}, F_{}); ++kt; }
+  tile(kt, F_{}, F_{});
+  // The compiler does not know the asm statements are MFMAs: left alone it reads accumulators
+  // (v_accvgpr_read for the epilogue) one cycle after the MFMA that produces them.  Re-define every
+  // accumulator tile in (empty) asm statements placed after the wait, so all reads are ordered behind it.
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]),
+                      "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#undef W4_FENCE
+#undef W4_BARRIER
+
+  if (p.act == VLB_ACT_SWIGLU_PAIR) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * TM + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(acc[i][j][e]) * acc[i][j + 1][e]);
+        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * TM + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + fq * 4;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+      }
+      if (p.act != VLB_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      }
+      if (p.residual) {
+        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+template <int ABL>
+int launch_w4(GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * (256 + 256) * ROW_BYTES;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+      return VLB_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_w4_kernel<ABL>), dim3(a.grid), dim3(256), LDS, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong wave groups, 2: four-wave 128x128 blocks,
+                        // 3 (default): four-wave kernel for long K (>= 4096), ping-pong otherwise
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 
@@ -502,7 +755,7 @@ int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>), dim3(a.grid), dim3(512), lds, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -520,8 +773,32 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     }
     configured = true;
   }
-  a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = a.N / BN;
+  if (a.grid == 0) {          // plain launch: the whole GEMM with BM x BN tiles
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = a.N / BN;
+    a.tile0 = 0; a.split_n = 1;
+    a.grid = a.tiles_m * a.tiles_n;
+  }
+  // the 4-wave kernel addresses operands with 32-bit byte offsets
+  const bool fits32 = (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31) &&
+                      (int64_t)a.M * a.lda2 < (1ll << 31) && (int64_t)a.N * a.ldw2 < (1ll << 31);
+  if constexpr (BM == 256 && BN == 256) {
+    if (!fits32 && (g_variant == 2 || (g_variant >= 0x20 && g_variant < 0x30))) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+    if (g_variant == 2) return launch_w4<0>(a, s);
+    // auto: the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and
+    // epilogue (one workgroup per CU, nothing to overlap them with): measured crossover K ~ 3072-4096
+    if (g_variant == 3) {
+      if (fits32 && a.K + a.K2 >= 4096) return launch_w4<0>(a, s);
+      return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+    }
+    if (g_variant == 0x21) return launch_w4<1>(a, s);     // timing-only ablations (wrong results)
+    if (g_variant == 0x22) return launch_w4<2>(a, s);
+    if (g_variant == 0x24) return launch_w4<4>(a, s);
+    if (g_variant == 0x27) return launch_w4<7>(a, s);
+    if (g_variant == 0x28) return launch_w4<8>(a, s);
+  } else {
+    if (g_variant == 2 || g_variant == 3 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+  }
   if (g_variant == 1 || (g_variant == 0 && a.act == VLB_ACT_SWIGLU_PAIR)) {
     return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
   }
@@ -539,7 +816,7 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     vlb_set_error("gemm: unknown kernel variant %d", g_variant);
     return VLB_ERR_INVALID;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.grid), dim3(512), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -599,7 +876,7 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   a.bias = (const bf16*)bias; a.residual = (const bf16*)residual;
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
-  a.act = act; a.tiles_m = 0; a.tiles_n = 0;
+  a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
@@ -608,26 +885,21 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   if (choice != 0 && g_force_tile == 1 && N % 256 == 0) choice = 1;
   if (choice != 0 && g_force_tile == 2 && N % 128 == 0) choice = 2;
   if (choice == 1) {
-    // Tail split: when the 256x256 grid ends in a mostly idle last wave of tiles (e.g. 640 tiles = 2.5
-    // waves for the N=4096 projections at M=10240), run the full waves with 256x256 tiles and the
-    // remaining rows with 256x128 tiles, which fill the chip for one shorter round instead.
+    // Tail split: when the 256x256 grid ends in a mostly idle last wave of tiles (e.g. 2576 tiles = 10.06
+    // waves for gate/up at M=5861), the full waves run as 256x256 tiles and the tiles of the partial wave
+    // are re-cut into 256x128 halves in a second launch, which spreads them over twice as many CUs for
+    // half as long.  Both launches walk the same tile order (map_tile), so the cut can be at any tile.
     const int cus = 256, tn = N / 256, tm = (M + 255) / 256;
     const int tiles = tm * tn, rem = tiles % cus;
-    if (g_tail_split && tiles > cus && rem != 0 && rem <= cus * 5 / 8 && cus % tn == 0) {
-      const int tm1 = (tiles / cus) * (cus / tn);          // row-tiles covered by the full waves
-      const int m1 = tm1 * 256;
-      if (m1 > 0 && m1 < M && M - m1 >= 128) {
-        GemmArgs hi = a, lo = a;
-        hi.M = m1;
-        lo.M = M - m1;
-        lo.A = a.A + (int64_t)m1 * a.lda;
-        lo.C = a.C + (int64_t)m1 * a.ldc;
-        if (a.A2) lo.A2 = a.A2 + (int64_t)m1 * a.lda2;
-        if (a.residual) lo.residual = a.residual + (int64_t)m1 * a.ldr;
-        int rc = launch_tile<256, 256, 2, 4>(hi, s);
-        if (rc != VLB_OK) return rc;
-        return launch_tile<256, 128, 4, 2>(lo, s);
-      }
+    if (g_tail_split && tiles > cus && rem != 0 && rem <= cus * 5 / 8) {
+      GemmArgs hi = a, lo = a;
+      hi.tiles_m = lo.tiles_m = tm;
+      hi.tiles_n = lo.tiles_n = tn;
+      hi.tile0 = 0; hi.split_n = 1; hi.grid = tiles - rem;
+      lo.tile0 = tiles - rem; lo.split_n = 2; lo.grid = 2 * rem;
+      int rc = launch_tile<256, 256, 2, 4>(hi, s);
+      if (rc != VLB_OK) return rc;
+      return launch_tile<256, 128, 4, 2>(lo, s);
     }
     return launch_tile<256, 256, 2, 4>(a, s);
   }
@@ -640,7 +912,7 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
 
 // tuning hooks (not part of the stable ABI): kernel variant / forced tile
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
-  g_variant = variant & 0xff;
+  g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;
   g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
 }

@@ -39,6 +39,41 @@ def test_gemm_shapes(dev, M, N, K):
     assert rel_err(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K,K2", [
+    (600, 512, 4096, 0),      # long K -> four-wave 128x128-block kernel, M tail
+    (600, 256, 4096, 64),     # ... with the LoRA operand pair appended to the K loop
+    (4500, 4096, 128, 0),     # 288 tiles = 1.125 waves -> tail split (ping-pong kernel + 256x128 halves)
+    (4500, 4096, 4096, 64),   # tail split behind the four-wave kernel, second operand pair
+])
+def test_gemm_long_k_and_tail_split(dev, M, N, K, K2):
+    from phantom_vlb_amd import ops
+    a, w = _r(M, K, dev=dev), _r(N, K, dev=dev, scale=0.05)
+    bias, res = _r(N, dev=dev), _r(M, N, dev=dev)
+    a2 = w2 = None
+    ref = a.float() @ w.float().t()
+    if K2:
+        a2, w2 = _r(M, K2, dev=dev, seed=3), _r(N, K2, dev=dev, scale=0.05, seed=4)
+        ref = ref + a2.float() @ w2.float().t()
+    out = ops.gemm(a, w, bias=bias, residual=res, act=ops.ACT_SILU, a2=a2, w2=w2)
+    y = F.silu(ref + bias.float()) + res.float()
+    assert rel_err(out, y) < 6e-3
+    # a row's result must not depend on how many rows the call has (packed layouts rely on it): the same
+    # rows through a differently tiled launch are bit-identical
+    half = ops.gemm(a[: M // 2 + 3], w, bias=bias, residual=res[: M // 2 + 3], act=ops.ACT_SILU,
+                    a2=None if a2 is None else a2[: M // 2 + 3], w2=w2)
+    assert torch.equal(half, out[: M // 2 + 3])
+
+
+def test_gemm_swiglu_pair_long_k_tail_split(dev):
+    from phantom_vlb_amd import ops
+    M, ff, K = 4500, 2048, 4096
+    a = _r(M, K, dev=dev)
+    wg, wu = _r(ff, K, dev=dev, scale=0.03, seed=1), _r(ff, K, dev=dev, scale=0.03, seed=2)
+    out = ops.gemm(a, ops.interleave_gate_up(wg, wu), act=ops.ACT_SWIGLU_PAIR)
+    ref = F.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert rel_err(out, ref) < 8e-3
+
+
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_gemm_epilogue(dev, act):
     from phantom_vlb_amd import ops

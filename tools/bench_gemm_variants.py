@@ -42,7 +42,7 @@ def main():
                 errs[v] = float((out[:256].float() - ref).abs().max() / ref.abs().max())
         print(f"{name:8s} M={M} N={N} K={K}: " + "  ".join(
             f"v{v}: {best[v]:.3f}ms {2.0 * M * N * K / best[v] / 1e9:7.1f}TF err={errs[v]:.0e}" for v in variants), flush=True)
-    lib.vlb_gemm_set_variant(1, 0)
+    lib.vlb_gemm_set_variant(3, 0)
 
 
 if __name__ == "__main__":

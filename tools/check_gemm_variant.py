@@ -17,7 +17,8 @@ ok = True
 for rep in range(3):
     for (M, N, K, K2) in [(512, 256, 128, 0), (1000, 512, 192, 0), (300, 256, 64, 0), (2048, 1024, 640, 0),
                           (768, 512, 256, 64), (4096, 4096, 4096, 0), (10240, 6144, 4096, 0), (1184, 256, 32, 0),
-                          (5000, 768, 96, 32), (256, 256, 32, 0), (256, 512, 64, 0), (260, 256, 160, 0)]:
+                          (5000, 768, 96, 32), (256, 256, 32, 0), (256, 512, 64, 0), (260, 256, 160, 0),
+                          (4500, 4096, 256, 0), (4500, 4096, 4096, 64), (5861, 4096, 4096, 0)]:   # tail-split cuts
         lib.vlb_gemm_set_variant(v, 0)
         g = torch.Generator(device=dev).manual_seed(M + N + K + rep)
         a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
@@ -38,6 +39,6 @@ for rep in range(3):
         ok = ok and err < 6e-3
         if rep == 0 or err >= 6e-3:
             print(f"{flag} v{v} M={M} N={N} K={K} K2={K2} kernel={choice} err={err:.2e}", flush=True)
-lib.vlb_gemm_set_variant(1, 0)
+lib.vlb_gemm_set_variant(3, 0)
 print("ALL OK" if ok else "FAILURES")
 sys.exit(0 if ok else 1)
