@@ -209,7 +209,8 @@ int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, cons
  * seeds_host: R/16 host uint32 (may be NULL when drop_p == 0). */
 int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M, int K, int R, float scale,
                   float drop_p, const uint32_t* seeds_host, void* stream);
-/* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K, >=R] bf16 (transposed adapters, row stride ldat). */
+/* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K, >=R] bf16 (transposed adapters, row stride ldat).
+ * K % 64 == 0, dx 16-byte aligned with lddx % 8 == 0. */
 int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
                        const uint32_t* seeds_host, void* stream);
 /* Skinny weight gradient (MFMA, both operands read transposed from LDS):

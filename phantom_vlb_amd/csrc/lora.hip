@@ -21,74 +21,112 @@ __device__ __forceinline__ uint32_t drop_bits_pair(uint32_t seed, int64_t m, int
   const uint64_t c = (uint64_t)m * (uint64_t)(K >> 1) + (uint64_t)kpair;
   return lowbias32((uint32_t)c ^ lowbias32((uint32_t)(c >> 32) + seed));
 }
+// Same bits when the whole activation has fewer than 2^32 column pairs (every shape of this model): the
+// high word of the counter is 0, so its hash `key` = lowbias32(seed) is a per-seed constant (host side)
+// and the counter is 32-bit arithmetic.  Kernels pick this path with the uniform flag Seeds::fast.
+__device__ __forceinline__ uint32_t drop_bits_fast(uint32_t key, uint32_t row_base, int kpair) {
+  return lowbias32((row_base + (uint32_t)kpair) ^ key);
+}
+
+struct Seeds { uint32_t s[8]; uint32_t key[8]; uint32_t fast; };
+
+__device__ __forceinline__ uint32_t drop_bits(const Seeds& sd, int g, int64_t m, int K, int kpair) {
+  return sd.fast ? drop_bits_fast(sd.key[g], (uint32_t)m * (uint32_t)(K >> 1), kpair) : drop_bits_pair(sd.s[g], m, K, kpair);
+}
 // keep flags of 8 consecutive columns starting at k0 (k0 % 8 == 0)
-__device__ __forceinline__ void keep8(uint32_t seed, int64_t m, int K, int k0, uint32_t thresh, bool (&keep)[8]) {
+__device__ __forceinline__ void keep8(const Seeds& sd, int g, int64_t m, int K, int k0, uint32_t thresh, bool (&keep)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint32_t h = drop_bits_pair(seed, m, K, (k0 >> 1) + q);
+    const uint32_t h = drop_bits(sd, g, m, K, (k0 >> 1) + q);
     keep[2 * q] = (h & 0xffffu) >= thresh;
     keep[2 * q + 1] = (h >> 16) >= thresh;
   }
 }
 
-struct Seeds { uint32_t s[8]; };
-
 // ---------------------------------------------------------------- t = scale * drop(x) . A^T
-// one block = 16 rows of x; its 4 waves each take a quarter of K (4 independent loads in flight per
-// wave) and the partial 16x16 tiles are summed through LDS.  MFMA rows = adapter ranks, cols = rows of x.
+// one block = 32 rows of x (two MFMA row tiles share every adapter fragment); its 8 waves each take an
+// eighth of K with 4 k-steps of loads in flight, and the partial 16x16 tiles are summed through LDS in a
+// fixed order.  MFMA rows = adapter ranks, cols = rows of x.
+constexpr int LD_RT = 2;      // row tiles per block
+constexpr int LD_WAVES = 8;
 template <int G>   // number of 16-rank groups (projections sharing this x)
-__global__ __launch_bounds__(256) void lora_down_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ A,
+__global__ __launch_bounds__(64 * LD_WAVES) void lora_down_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ A,
                                                         bf16* __restrict__ t, int ldt, int M, int K, float scale,
                                                         uint32_t thresh, Seeds seeds) {
-  __shared__ float red[3][G][4][64];
+  __shared__ float red[LD_WAVES - 1][G][LD_RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = blockIdx.x * 16;
+  const int m0 = blockIdx.x * 16 * LD_RT;
   const int fr = lane & 15, fq = lane >> 4;
-  const int m = min(m0 + fr, M - 1);
-  f32x4 acc[G];
+  int m[LD_RT];
+  const bf16* xr[LD_RT];
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16* xr = x + (int64_t)m * ldx + fq * 8;
-  const int kq = ((K / 32 + 3) / 4) * 32;            // K range of this wave, a multiple of 32
+  for (int r = 0; r < LD_RT; ++r) {
+    m[r] = min(m0 + 16 * r + fr, M - 1);
+    xr[r] = x + (int64_t)m[r] * ldx + fq * 8;
+  }
+  f32x4 acc[G][LD_RT];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int r = 0; r < LD_RT; ++r) acc[g][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kq = ((K / 32 + LD_WAVES - 1) / LD_WAVES) * 32;     // K range of this wave, a multiple of 32
   const int kbeg = wave * kq, kend = min(K, kbeg + kq);
+  const bf16* ar = A + (int64_t)fr * K + fq * 8;
 #pragma unroll 4
   for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + k0);
+    bf16x8 xf[LD_RT], af[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + (int64_t)(16 * g + fr) * K + k0 + fq * 8);
-      bf16x8 xm = xf;
-      if (thresh != 0) {
-        bool keep[8];
-        keep8(seeds.s[g], m, K, k0 + fq * 8, thresh, keep);
+    for (int r = 0; r < LD_RT; ++r) xf[r] = *reinterpret_cast<const bf16x8*>(xr[r] + k0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xm[j] = keep[j] ? xf[j] : (bf16)0.f;
+    for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const bf16x8*>(ar + (int64_t)16 * g * K + k0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < LD_RT; ++r) {
+        bf16x8 xm = xf[r];
+        if (thresh != 0) {
+          bool keep[8];
+          keep8(seeds, g, m[r], K, k0 + fq * 8, thresh, keep);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xm[j] = keep[j] ? xf[r][j] : (bf16)0.f;
+        }
+        acc[g][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], xm, acc[g][r], 0, 0, 0);
       }
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm, acc[g], 0, 0, 0);
-    }
   }
   if (wave > 0) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[wave - 1][g][e][lane] = acc[g][e];
+      for (int r = 0; r < LD_RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave - 1][g][r][e][lane] = acc[g][r][e];
   }
   __syncthreads();
-  if (wave == 0 && m0 + fr < M) {
+  if (wave == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      bf16x4 o;
+    for (int r = 0; r < LD_RT; ++r) {
+      if (m0 + 16 * r + fr >= M) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = (bf16)((acc[g][e] + red[0][g][e][lane] + red[1][g][e][lane] + red[2][g][e][lane]) * scale);
-      *reinterpret_cast<bf16x4*>(t + (int64_t)(m0 + fr) * ldt + 16 * g + fq * 4) = o;
+      for (int g = 0; g < G; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[g][r][e];
+#pragma unroll
+          for (int w = 0; w < LD_WAVES - 1; ++w) v += red[w][g][r][e][lane];
+          o[e] = (bf16)(v * scale);
+        }
+        *reinterpret_cast<bf16x4*>(t + (int64_t)(m0 + 16 * r + fr) * ldt + 16 * g + fq * 4) = o;
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------- dx += keep/(1-p) * (u . A)
-// At[K][R] is the transposed adapter (row = input column).  One wave = 16 rows x 16 columns per MFMA;
-// a wave walks 16 rows x 256 columns.
+// At[K][R] is the transposed adapter (row = input column).  A wave walks 16 rows x 256 columns in steps of
+// 64 columns = four MFMAs whose A-operand rows are permuted so that a lane ends up with 16 CONSECUTIVE
+// columns of its row (MFMA t, output row i <-> column 16*(i/4) + 4t + i%4): the read-modify-write of dx is
+// two 16-byte accesses per lane and the four lanes of a row cover one 128-byte line.
 template <int G>
 __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u, int ldu, const bf16* __restrict__ At, int ldat,
                                                       bf16* __restrict__ dx, int lddx, int M, int K, float inv_keep,
@@ -99,6 +137,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
   if (kbase >= K) return;
   const int fr = lane & 15, fq = lane >> 4;
   const int m = min(m0 + fr, M - 1);
+  const bool live = m0 + fr < M;
   // B operand: u[m][16g + 8fq .. +8] for fq < 2, zeros for the padded half of the k=32 step
   bf16x8 uf[G];
 #pragma unroll
@@ -106,35 +145,52 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
     uf[g] = bf16x8{};
     if (fq < 2) uf[g] = *reinterpret_cast<const bf16x8*>(u + (int64_t)m * ldu + 16 * g + 8 * fq);
   }
-  for (int kc = 0; kc < 256 && kbase + kc < K; kc += 16) {
+  const int arow = 16 * (fr >> 2) + (fr & 3);          // + 4t: At row (relative to kcol) feeding MFMA t, output row fr
+  bf16* prow = dx + (int64_t)m * lddx + 16 * fq;
+  bf16x8 old0 = *reinterpret_cast<const bf16x8*>(prow + kbase);
+  bf16x8 old1 = *reinterpret_cast<const bf16x8*>(prow + kbase + 8);
+  for (int kc = 0; kc < 256 && kbase + kc < K; kc += 64) {
     const int kcol = kbase + kc;
-    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 nx0 = old0, nx1 = old1;
+    if (kc + 64 < 256 && kcol + 64 < K) {               // next step's dx is in flight during this step's math
+      nx0 = *reinterpret_cast<const bf16x8*>(prow + kcol + 64);
+      nx1 = *reinterpret_cast<const bf16x8*>(prow + kcol + 72);
+    }
+    float sum[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      bf16x8 af = bf16x8{};
-      if (fq < 2) af = *reinterpret_cast<const bf16x8*>(At + (int64_t)(kcol + fr) * ldat + 16 * g + 8 * fq);
-      f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, uf[g], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      // lane holds columns kcol + 4fq + {0..3} of row m0 + fr
-      if (thresh != 0) {
-        const int kk = kcol + 4 * fq;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const uint32_t h = drop_bits_pair(seeds.s[g], m, K, (kk >> 1) + q);
-          if ((h & 0xffffu) < thresh) d[2 * q] = 0.f;
-          if ((h >> 16) < thresh) d[2 * q + 1] = 0.f;
+      for (int t = 0; t < 4; ++t) {
+        bf16x8 af = bf16x8{};
+        if (fq < 2) af = *reinterpret_cast<const bf16x8*>(At + (int64_t)(kcol + arow + 4 * t) * ldat + 16 * g + 8 * fq);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, uf[g], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // lane holds columns kcol + 16fq + 4t + {0..3} of row m
+        if (thresh != 0) {
+          const int kk = kcol + 16 * fq + 4 * t;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t h = drop_bits(seeds, g, m, K, (kk >> 1) + q);
+            if ((h & 0xffffu) < thresh) d[2 * q] = 0.f;
+            if ((h >> 16) < thresh) d[2 * q + 1] = 0.f;
+          }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[4 * t + e] += d[e] * inv_keep;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sum[e] += d[e] * inv_keep;
     }
-    if (m0 + fr < M) {
-      bf16* p = dx + (int64_t)(m0 + fr) * lddx + kcol + 4 * fq;
-      const bf16x4 old = *reinterpret_cast<const bf16x4*>(p);
-      bf16x4 o;
+    if (live) {
+      bf16x8 o0, o1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)((float)old[e] + sum[e]);
-      *reinterpret_cast<bf16x4*>(p) = o;
+      for (int e = 0; e < 8; ++e) {
+        o0[e] = (bf16)((float)old0[e] + sum[e]);
+        o1[e] = (bf16)((float)old1[e] + sum[8 + e]);
+      }
+      *reinterpret_cast<bf16x8*>(prow + kcol) = o0;
+      *reinterpret_cast<bf16x8*>(prow + kcol + 8) = o1;
     }
+    old0 = nx0; old1 = nx1;
   }
 }
 
@@ -229,10 +285,19 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       for (int g = 0; g < G; ++g) {
         bf16x8 xm = xf;
         if (thresh != 0) {
+          // lanes fr and fr^1 hold the two columns of one hashed pair: the even lane hashes rows 0..3, the
+          // odd lane rows 4..7, and they swap results (quad_perm [1,0,3,2]) - half the hashes per lane
+          const bool odd = col & 1;
+          uint32_t hm[4], ho[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            hm[jj] = drop_bits(seeds, g, m0 + 8 * fq + (odd ? 4 : 0) + jj, K, col >> 1);
+            ho[jj] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm[jj], 0xB1, 0xf, 0xf, true);
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const uint32_t hsh = drop_bits_pair(seeds.s[g], m0 + 8 * fq + j, K, col >> 1);
-            const uint32_t bits = (col & 1) ? (hsh >> 16) : (hsh & 0xffffu);
+            const uint32_t hsh = (j < 4) == !odd ? hm[j & 3] : ho[j & 3];
+            const uint32_t bits = odd ? (hsh >> 16) : (hsh & 0xffffu);
             if (bits < thresh) xm[j] = (bf16)0.f;
           }
         }
@@ -264,6 +329,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+inline uint32_t lowbias32_host(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+inline Seeds make_seeds(const uint32_t* seeds_host, int groups, int M, int K) {
+  Seeds sd{};
+  for (int g = 0; g < groups; ++g) {
+    sd.s[g] = seeds_host ? seeds_host[g] : 0u;
+    sd.key[g] = lowbias32_host(sd.s[g]);
+  }
+  sd.fast = ((int64_t)M * (K >> 1) < (1ll << 32)) ? 1u : 0u;
+  return sd;
+}
 inline uint32_t thresh16(float p) {
   if (p <= 0.f) return 0;
   uint32_t t = (uint32_t)(p * 65536.f + 0.5f);
@@ -287,8 +365,7 @@ extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, 
   const int splits = vlb_wgrad_splits(M);
   const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
   const float inv_keep = 1.f / (1.f - drop_p);
-  Seeds sd{};
-  for (int g = 0; g < N / 16; ++g) sd.s[g] = seeds_host ? seeds_host[g] : 0u;
+  const Seeds sd = make_seeds(seeds_host, N / 16, M, K);
   dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
   const uint32_t th = thresh16(drop_p);
   switch (N / 16) {
@@ -310,16 +387,15 @@ extern "C" int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int
   VLB_REQUIRE(M > 0 && K % 32 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldx % 8 == 0 && ldt % 4 == 0,
               "lora_down: bad shape M=%d K=%d R=%d", M, K, R);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "lora_down: bad dropout arguments");
-  Seeds s{};
-  for (int g = 0; g < R / 16; ++g) s.s[g] = seeds_host ? seeds_host[g] : 0u;
+  const Seeds s = make_seeds(seeds_host, R / 16, M, K);
   const float sc = scale / (1.f - drop_p);
-  dim3 grid((M + 15) / 16);
+  dim3 grid((M + 16 * LD_RT - 1) / (16 * LD_RT));
   hipStream_t st = as_stream(stream);
   const uint32_t th = thresh16(drop_p);
   switch (R / 16) {
-    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
-    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
-    default: hipLaunchKernelGGL(lora_down_kernel<3>, grid, dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
+    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
+    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
+    default: hipLaunchKernelGGL(lora_down_kernel<3>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
   }
   VLB_LAUNCH_CHECK();
   return VLB_OK;
@@ -328,11 +404,11 @@ extern "C" int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int
 extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R,
                                   float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(u && At && dx, "lora_dx_masked: null operand");
-  VLB_REQUIRE(M > 0 && K % 16 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldu % 8 == 0 && lddx % 4 == 0 && ldat % 8 == 0 && ldat >= R,
+  VLB_REQUIRE(M > 0 && K % 64 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldu % 8 == 0 && lddx % 8 == 0 && ldat % 8 == 0 && ldat >= R &&
+                  ((uintptr_t)dx % 16) == 0,
               "lora_dx_masked: bad shape M=%d K=%d R=%d", M, K, R);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "lora_dx_masked: bad dropout arguments");
-  Seeds s{};
-  for (int g = 0; g < R / 16; ++g) s.s[g] = seeds_host ? seeds_host[g] : 0u;
+  const Seeds s = make_seeds(seeds_host, R / 16, M, K);
   dim3 grid((K + 1023) / 1024, (M + 15) / 16);
   hipStream_t st = as_stream(stream);
   const uint32_t th = thresh16(drop_p);
