@@ -1,11 +1,12 @@
 """Headline benchmark: clips/sec of one fine-tuning step (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 10 --warmup 3          # configs[1]: 7B frozen backbone + 2k head, B=5/GPU
+  python bench.py --gpus 1 --steps 8 --warmup 2            # configs[2]: 7B + LoRA r=16 + 2k head, B=3/GPU (the metric's config)
+  python bench.py --workload frozen                        # configs[1]: 7B frozen backbone + 2k head, B=5/GPU
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = forward through CLIP tower + STC connector + splice + 32 Mistral layers + brain head,
-head backward, global-norm clip, AdamW, cosine LR - all on libvlb HIP kernels, inputs resident in
-HBM.  One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+A "step" = forward through CLIP tower + STC connector + splice + 32 Mistral layers (+LoRA) + brain head,
+backward through head and decoder (LoRA A/B gradients), global-norm clip, AdamW, cosine LR - all on
+libvlb HIP kernels, inputs resident in HBM.  One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
 the 256x256 MFMA GEMM on the gate/up projection, timed with HIP events on its own stream inside the
 timed region) and `cpu_baseline` (the oracle on the host cores, bounded sample, N=1 only).
 """
@@ -25,8 +26,9 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
 # L2->fabric bytes of ONE gate/up GEMM launch at B=5, measured offline with rocprofv3 --pmc (separate FETCH_SIZE /
 # WRITE_SIZE passes, gfx950 2x read correction): profiles/r01_gemm_gateup_hbm_traffic.csv.  Only valid for that shape.
-GATEUP_TRAFFIC_BYTES = {(10240, 28672, 4096): 3.904e9,     # dense rows (--no-pack)
-                        (9447, 28672, 4096): 4.060e9}      # packed rows of the default synthetic batch (r01_..._packed.csv)
+GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 2.495e9,     # default (LoRA, packed rows): profiles/r01_gemm_gateup_hbm_traffic_lora.csv
+                        (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows: ..._frozen_w4.csv
+                        (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: ..._traffic.csv
 # algorithmic TFLOP per clip
 TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8}
 
@@ -36,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="frozen", choices=["frozen", "lora"])
+    ap.add_argument("--workload", default="lora", choices=["frozen", "lora"],
+                    help="lora = BASELINE configs[2], the configuration the metric names (default); frozen = configs[1]")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
     ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,12 +182,16 @@ def main():
                          f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_bf16 call", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
-                         "traffic_note": "L2->fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic*.csv); "
-                         f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)",
+                         "traffic_note": "L2->fabric bytes of the main launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic*.csv); "
+                         + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN:.3e} (A | t, W | B, C [M,N] bf16)" if lora else
+                            f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":
             v, cores, sample = cpu_baseline(g, cfg.num_target)
+            if lora:      # the oracle sample is forward only; the LoRA step adds dgrad + attention/LoRA backward
+                v = v * TFLOP_PER_CLIP["frozen"] / TFLOP_PER_CLIP["lora"]
+                sample += f"; LoRA step scaled by algorithmic FLOPs {TFLOP_PER_CLIP['lora']}/{TFLOP_PER_CLIP['frozen']} (backward not timed)"
             out["cpu_baseline"] = {"value": round(v, 6), "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
         print(json.dumps(out), flush=True)
     if use_dist:

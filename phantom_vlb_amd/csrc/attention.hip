@@ -309,6 +309,7 @@ namespace {
 constexpr int BK_KEYS = 128;   // keys per workgroup
 constexpr int BQ = 32;         // queries per inner block
 
+int g_attn_ablate = 0;
 struct AttnBwdArgs {
   const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
   const float* lse; const float* delta; const uint8_t* mask; const int* cu;
@@ -316,6 +317,7 @@ struct AttnBwdArgs {
   int ldq, ldk, ldv, lddo, lddk, lddv;
   int B, S, Hq, Hkv;
   float scale;
+  int ablate;      // timing-only experiments (wrong results): bit0 skip dQ atomics, bit1 skip the whole dQ phase
 };
 
 __device__ __forceinline__ int sw2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
     // raw barrier: __syncthreads() would add vmcnt(0) and drain the in-flight DMA and atomics
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // dS^T images complete
-    if (active) {
+    if (active && !(p.ablate & 2)) {
       // ---- dQ[:, 32*w4 .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
       f32x16 dq;
 #pragma unroll
@@ -555,11 +557,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int qi = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = qi < Sb;
-        atomicAdd(dqp + (int64_t)min(qi, Sb - 1) * p.Hq * D, ok ? dq[r] : 0.f);
+        if (!(p.ablate & 1)) atomicAdd(dqp + (int64_t)min(qi, Sb - 1) * p.Hq * D, ok ? dq[r] : 0.f);
+        else if (dq[r] == 12345.678f) dqp[0] = 1.f;      // keep the MFMAs alive
       }
       // the next tile's DMA (issued at the top of this iteration) is older than the 16 atomics:
       // vmcnt(16) retires it and leaves the atomics in flight across the barrier.
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (!(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -634,7 +638,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
   if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
-                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale};
+                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale, g_attn_ablate};
   constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
   static bool configured = false;
   if (!configured) {
@@ -653,3 +657,6 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
+
+// tuning hook (not part of the stable ABI): timing-only ablations of the attention backward kernel
+extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits; }

@@ -6,7 +6,8 @@
 
 Units are KB (MI355X_MICROARCH.md, HBM section); on gfx950 FETCH_SIZE under-reports wide coalesced
 reads by 2x, so traffic = (2*FETCH + WRITE) * 1024 bytes per launch.  The gate/up launches are
-picked as the gemm_pp_kernel<256,256> launches with the largest grid.
+picked as the gemm_w4_kernel launches with the largest grid (the main launch of each gate/up call; its
+256x128 tail launch, if any, is not included).
 """
 import csv
 import glob
@@ -19,7 +20,7 @@ def rows(d):
 
 
 def pick(rs, counter):
-    gemm = [r for r in rs if "gemm_pp_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    gemm = [r for r in rs if "gemm_w4_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
     grid = max(int(r["Grid_Size"]) for r in gemm)
     if len(sys.argv) > 3:
         grid = int(sys.argv[3]) * 512
