@@ -213,6 +213,12 @@ int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M
  * K % 64 == 0, dx 16-byte aligned with lddx % 8 == 0. */
 int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
                        const uint32_t* seeds_host, void* stream);
+/* Rebuild derived adapter layouts after an optimiser step in ONE launch.  jobs: device array of n_jobs
+ * records {const bf16* src; bf16* dst; int32 n; int32 n0; int32 ld; int32 pad} (32 bytes): rows
+ * [n0, n0+256) of the transpose of the row-major [16, n] matrix `src` are written to dst[i*ld + 0..15]
+ * (dst points at the first row/column of the 16-column band, 16-byte aligned, ld % 8 == 0).
+ * Used for At[:, 16j:16j+16] = A_j^T and Bpad[row0:row0+N, 16j:16j+16] = B_j (peft: lora_A / lora_B). */
+int vlb_transpose16_scatter(const void* jobs, int n_jobs, void* stream);
 /* Skinny weight gradient (MFMA, both operands read transposed from LDS):
  *   dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep_g(X[m,k]) + beta * dW ;  N in {16,32,48}, g = n/16.
  * dA of all projections sharing x in one launch (G = [u_q|u_k|u_v], X = x, one dropout seed per

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vlb_head_ws_floats": [I, I, I, I],
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P, I, P],
+    "vlb_transpose16_scatter": [P, I, P],
     "vlb_wgrad_splits": [I],
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
     "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],

@@ -329,6 +329,27 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// ---------------------------------------------------------------- derived adapter layouts
+// Every derived layout is "a [16, n] bf16 matrix written transposed into 16 columns of an [n, ld] image":
+// A_j [16,K] -> A^T padded (At[:, 16j:16j+16]) and B_j^T [16,N] -> the block-diagonal padded B
+// (Bpad[row0:row0+N, 16j:16j+16]).  One launch walks a device table of 256-row jobs.
+struct ScatterJob { const bf16* src; bf16* dst; int n; int n0; int ld; int pad; };   // dst already at (row0, col0)
+
+__global__ __launch_bounds__(256) void transpose16_scatter_kernel(const ScatterJob* __restrict__ jobs) {
+  const ScatterJob j = jobs[blockIdx.x];
+  const int i = j.n0 + threadIdx.x;
+  if (i >= j.n) return;
+  bf16x8 lo, hi;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    lo[r] = j.src[(int64_t)r * j.n + i];
+    hi[r] = j.src[(int64_t)(r + 8) * j.n + i];
+  }
+  bf16* d = j.dst + (int64_t)i * j.ld;
+  *reinterpret_cast<bf16x8*>(d) = lo;
+  *reinterpret_cast<bf16x8*>(d + 8) = hi;
+}
+
 inline uint32_t lowbias32_host(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -418,6 +439,13 @@ extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ld
     case 2: hipLaunchKernelGGL(lora_dx_kernel<2>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
     default: hipLaunchKernelGGL(lora_dx_kernel<3>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
   }
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_transpose16_scatter(const void* jobs, int n_jobs, void* stream) {
+  VLB_REQUIRE(jobs && n_jobs > 0, "transpose16_scatter: empty job table");
+  hipLaunchKernelGGL(transpose16_scatter_kernel, dim3(n_jobs), dim3(256), 0, as_stream(stream), (const ScatterJob*)jobs);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
