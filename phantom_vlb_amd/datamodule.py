@@ -151,8 +151,9 @@ class VLBDataModule(_Base):
     def x_dataloader(self, dataset, shuffle: bool = True, sampler=None):
         if dataset is None:
             raise AttributeError
+        # pinned batches so DevicePrefetcher's host->device copies are truly asynchronous
         return DataLoader(dataset=dataset, batch_size=self.config.batch_size, shuffle=shuffle and sampler is None,
-                          sampler=sampler, num_workers=self.config.num_workers)
+                          sampler=sampler, num_workers=self.config.num_workers, pin_memory=torch.cuda.is_available())
 
     def train_dataloader(self, rank: int = 0, world: int = 1):
         sampler = None
@@ -164,3 +165,47 @@ class VLBDataModule(_Base):
 
     def val_dataloader(self):
         return self.x_dataloader(dataset=self.datasets.val, shuffle=self.config.shuffle_val_data)
+
+
+class DevicePrefetcher:
+    """Iterates a DataLoader one batch ahead of the consumer: the large tensors of batch i+1 (16.3 MB of fp32
+    pixels per clip) are copied host->device on a side stream while step i computes, and are
+    handed over with an event, so the step never waits on PCIe.  The token ids and ``padvals`` stay on the
+    host: the step sizes its unpadded row layout from them without a device sync (they are tiny and are
+    uploaded by the step itself).  Device tensors are tied to the consumer stream with ``record_stream`` so
+    the caching allocator cannot recycle them while a kernel still reads them."""
+
+    def __init__(self, loader, device, keep_on_host=("language", "padvals")):
+        self.loader, self.device, self.keep = loader, torch.device(device), tuple(keep_on_host)
+        self.sampler = getattr(loader, "sampler", None)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        out, ev = {}, torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            for k, v in batch.items():
+                out[k] = v if (k in self.keep or not torch.is_tensor(v)) else v.to(self.device, non_blocking=True)
+            ev.record(self.stream)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))          # batch i+1 starts moving before step i is enqueued
+            except StopIteration:
+                nxt = None
+            consumer = torch.cuda.current_stream(self.device)
+            consumer.wait_event(ev)
+            for v in cur.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(consumer)
+            yield cur

@@ -147,6 +147,9 @@ class Trainer:
         except TypeError:
             train_loader = datamodule.train_dataloader()
         val_loader = datamodule.val_dataloader()
+        if torch.cuda.is_available():        # overlap the next batch's host->device copy with the current step
+            from .datamodule import DevicePrefetcher
+            train_loader = DevicePrefetcher(train_loader, model.device)
         n_batches = len(train_loader)
         val_every = max(1, int(n_batches * self.val_check_interval)) if self.val_check_interval <= 1 else int(self.val_check_interval)
         t0 = time.time()

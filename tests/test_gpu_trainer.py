@@ -113,3 +113,25 @@ def test_upstream_named_safetensors_checkpoint_loads(dev, tmp_path):
     pa = a.validation_step(batch)["brain_preds"]
     pb = b.validation_step(batch)["brain_preds"]
     assert torch.equal(pa, pb)
+
+
+def test_device_prefetcher_hands_over_identical_batches(dev):
+    """Side-stream H2D prefetch: same values as the plain loader, big tensors on the device, ids / padvals
+    left on the host (the packed row layout is sized from them without a sync)."""
+    from phantom_vlb_amd.datamodule import DevicePrefetcher, VLBDataModule, VLBDataModuleConfig
+    dm = VLBDataModule(VLBDataModuleConfig(lazyload_path="synthetic:4x5", subject="sub-01", seasons=["s1"], delay=3,
+                                           window=3, random_state=1234, shuffle_val_data=False, batch_size=2,
+                                           geometry="mini", num_target=128))
+    loader = dm.val_dataloader()
+    plain = list(loader)
+    pre = list(DevicePrefetcher(loader, dev))
+    assert len(pre) == len(plain) > 1
+    for a, b in zip(plain, pre):
+        assert set(a) == set(b)
+        for k in a:
+            if k in ("language", "padvals"):
+                assert b[k].device.type == "cpu"
+            else:
+                assert b[k].is_cuda
+            assert torch.equal(a[k], b[k].cpu()), k
+    assert len(DevicePrefetcher(loader, dev)) == len(loader)
