@@ -85,7 +85,8 @@ def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)      # wraps only when rehearsing N ranks on fewer GPUs
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # VLB_FORCE_DIST=1 runs the multi-process code path (RCCL init, flat-bucket all-reduce, barriers)
@@ -95,7 +96,8 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(os.environ.get("VLB_DIST_BACKEND", "nccl"), device_id=dev)
+        backend = os.environ.get("VLB_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from phantom_vlb_amd import ops
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch

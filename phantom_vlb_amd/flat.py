@@ -24,6 +24,7 @@ class FlatTrainables:
         for n in head.master:
             entries.append((n, head.master[n].numel(), tuple(head.master[n].shape)))
         groups = []
+        self.layer_ranges = []                # per decoder layer: [start, end) of its LoRA tensors in the flat order
         if lora is not None:
             from .lora import GROUPS
             for li in range(len(lora.layers)):
@@ -38,6 +39,11 @@ class FlatTrainables:
             offs[n] = (off, k, shp)
             off += (k + 7) // 8 * 8              # keep every tensor 32-byte aligned (16 B in bf16)
         self.numel = off
+        if lora is not None:
+            for li in range(len(lora.layers)):
+                names = [n for n, _, _ in entries if n.startswith(f"model.layers.{li}.")]
+                first, last = offs[names[0]], offs[names[-1]]
+                self.layer_ranges.append((first[0], last[0] + (last[1] + 7) // 8 * 8))
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.compute = torch.zeros(off, dtype=BF16, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)

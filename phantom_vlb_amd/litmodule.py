@@ -96,7 +96,8 @@ class VLBLitModule(_Base):
     def __init__(self, config: VLBLitModuleConfig) -> None:
         super().__init__()
         self.config = config
-        self._device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        from .parallel import local_device_index
+        self._device = torch.device("cuda", local_device_index())
         self._step = 0
         self.world_size = 1
         self.rank = 0

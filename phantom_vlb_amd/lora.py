@@ -73,6 +73,7 @@ class LoraState:
         self.scale = alpha / r
         self.p = float(dropout)
         self.step = 0
+        self.grad_hook = None          # callable(layer index) fired by backward when a layer's gradients are final
         self.base_seed = seed
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         self.out_dims = {"self_attn.q_proj": qd, "self_attn.k_proj": kd, "self_attn.v_proj": kd, "self_attn.o_proj": g.dim,
@@ -287,4 +288,6 @@ class LoraState:
             d_h1 = self._group_backward(li, "qkv", dqkv, sv["h1"], sv["t_qkv"], sd[0:3], lw["wqkv_t"], need_dx)
             if need_dx:
                 dx = ops.rmsnorm_bwd(sv["x"], lw["in_norm"], d_h1, g.rms_eps, dx_in=dx2)
+            if self.grad_hook is not None:
+                self.grad_hook(li)            # data parallel: this layer's gradients are final
         self.saved = []

@@ -29,6 +29,14 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index() -> int:
+    """GPU of this process: LOCAL_RANK, wrapped onto the visible devices so that several ranks can
+    rehearse on a one-GPU box (gloo backend); on a real node every rank gets its own GPU."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return local % n if n > 0 else local
+
+
 def init_distributed(backend: str | None = None):
     """Initialise from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*). Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -38,7 +46,7 @@ def init_distributed(backend: str | None = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            kw["device_id"] = torch.device("cuda", local_device_index())
         dist.init_process_group(backend, **kw)
     return rank, world
 
@@ -57,6 +65,7 @@ class FlatGradReducer:
         total = sum(d[k].numel() for d, k in items)
         ref = items[0][0][items[0][1]]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self._pending = []
         off = 0
         for d, k in items:
             n = d[k].numel()
@@ -67,9 +76,35 @@ class FlatGradReducer:
 
     force = False     # rehearsal switch: reduce even when the group has a single rank
 
+    def _active(self):
+        return dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+
+    def reduce_range(self, start: int, end: int):
+        """Start the all-reduce of flat[start:end] NOW (asynchronously): called from the backward pass as soon as
+        a range of layers has its final gradients, so the exchange over xGMI overlaps the rest of backward.
+        The collective is ordered after everything already enqueued on the current stream."""
+        if not self._active() or end <= start:
+            return
+        work = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((start, end, work))
+
     def __call__(self, grads=None):
-        if dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1):
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        """Finish the step's reduction: ranges already started are waited for, the rest is reduced in as few
+        calls as possible (one, when nothing was started early)."""
+        if not self._active():
+            return
+        done = sorted((s, e) for s, e, _ in self._pending)
+        pos, n = 0, self.flat.numel()
+        for s, e in done + [(n, n)]:
+            if s > pos:
+                self._pending.append((pos, s, dist.all_reduce(self.flat[pos:s], op=dist.ReduceOp.SUM, group=self.group,
+                                                             async_op=True)))
+            pos = max(pos, e)
+        for _, _, work in self._pending:
+            work.wait()
+        self._pending = []
+
+    _pending: list = []
 
 
 def attach_data_parallel(module, optimizer, group=None):
@@ -77,7 +112,18 @@ def attach_data_parallel(module, optimizer, group=None):
     flat = getattr(module, "flat", None)
     if flat is not None:                     # the optimiser's flat gradient buffer IS the bucket
         reducer = FlatGradReducer.__new__(FlatGradReducer)
-        reducer.group, reducer.flat = group, flat.grad
+        reducer.group, reducer.flat, reducer._pending = group, flat.grad, []
+        lora = getattr(module, "lora", None)
+        if lora is not None and getattr(flat, "layer_ranges", None):
+            # overlap: when backward has finished layers [li, li+chunk) their slice of the bucket is reduced while
+            # the layers below are still being differentiated (backward walks li = L-1 .. 0)
+            chunk = max(1, len(flat.layer_ranges) // 4)
+
+            def on_layer_done(li, ranges=flat.layer_ranges, chunk=chunk):
+                if li % chunk == 0:
+                    hi = min(li + chunk, len(ranges)) - 1
+                    reducer.reduce_range(ranges[li][0], ranges[hi][1])
+            lora.grad_hook = on_layer_done
     else:
         dicts = [module.head.grads]
         if getattr(module, "lora", None) is not None:

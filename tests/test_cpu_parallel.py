@@ -53,6 +53,32 @@ def test_flat_grad_reducer_sums_over_ranks():
         assert torch.allclose(g0[k], expect) and torch.allclose(g1[k], expect)
 
 
+def _flat_reduce_overlapped(rank, world):
+    """Ranges started early (as backward finishes layer groups) + the final call == one whole-bucket reduce,
+    every element reduced exactly once."""
+    from phantom_vlb_amd.parallel import FlatGradReducer
+    torch.manual_seed(10 + rank)
+    grads = {f"t{i}": torch.randn(11 + i) for i in range(9)}
+    before = torch.cat([v.reshape(-1) for v in grads.values()]).clone()
+    red = FlatGradReducer([grads])
+    n = red.flat.numel()
+    red.reduce_range(n - 30, n)             # "layers 24..31"
+    red.reduce_range(40, n - 30)            # "layers 8..23"
+    red.reduce_range(40, 40)                # empty range: ignored
+    red()                                   # head + the remaining prefix, then waits
+    assert red._pending == []
+    red2 = red.flat.clone()
+    red()                                   # a second call with nothing started reduces the whole bucket once more
+    return red2, red.flat.clone(), before
+
+
+def test_flat_grad_reducer_overlapped_ranges():
+    out = _run(_flat_reduce_overlapped)
+    (r0, again0, b0), (r1, again1, b1) = out[0], out[1]
+    assert torch.allclose(r0, b0 + b1) and torch.allclose(r1, b0 + b1)          # each element exactly once
+    assert torch.allclose(again0, 2 * (b0 + b1)) and torch.allclose(again1, again0)
+
+
 def _dp_identity(rank, world):
     """sum over ranks of grad(mse_r/world + l2/world) == grad of the single-process objective on the
     concatenated batch (ridge penalty counted once) - checked with the oracle's head on CPU."""
