@@ -514,12 +514,19 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
                : "v"(__builtin_bit_cast(i32x4_t, a)), "v"(__builtin_bit_cast(i32x4_t, b)));
 }
 
-template <int ABL = 0>
+// NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
+// of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.
+template <int NT = 8, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, TM = 128, TN = 128, MT = 8, NT = 8;
+  constexpr int MT = 8, TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
+  constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
+  constexpr int LAST_A = NG / 2 + 1;                   // group in which the double-slotted last A fragment is fetched
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int A_LD = BM / 32, B_LD = BN / 32;       // LDS-DMA instructions per thread per tile (32 rows each)
+  constexpr int ND = A_LD + B_LD;
+  static_assert(NT == 8 || NT == 4, "wave block 128x128 or 128x64");
+  static_assert(ND <= 2 * NG && (NT - 1) < NG && (2 * (MT - 2) + 2) * NT / 8 < NG, "schedule does not fit the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int m0, n0;
@@ -592,7 +599,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     select(1);
 #pragma unroll
     for (int i = 0; i < A_LD + B_LD; ++i) dma(1, i);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed; tile 1 may still fly
+    if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed; tile 1 may still fly
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -618,15 +626,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
     // ---------------- block 1: MFMA(k-step 0) || reads of k-step 1
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < NG; ++g) {
       if (!(ABL & 2) || kt == 0) {
-        if (g < 8) wf[1][g] = frag(sb, b_off[1], g);
-        if (g >= 2 && (g & 1) == 0) af[g / 2 - 1] = frag(sb, a_off[1], g / 2 - 1);     // af[i] died in group 2i+1
-        if (g == 9) a7[1] = frag(sb, a_off[1], MT - 1);
+        if (g < NT) wf[1][g] = frag(sb, b_off[1], g);
+        // af[i] dies with MFMA i*NT + NT-1, i.e. in group (i*NT + NT-1)/4; it is refetched in the next group
+        if (g >= 1 && (g * 4) % NT == 0 && g * 4 / NT - 1 <= MT - 2) af[g * 4 / NT - 1] = frag(sb, a_off[1], g * 4 / NT - 1);
+        if (g == LAST_A) a7[1] = frag(sb, a_off[1], MT - 1);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int t = g * 4 + q, i = t >> 3, j = t & 7;
+        const int t = g * 4 + q, i = t / NT, j = t % NT;
         mfma_tied(acc[i][j], wf[0][j], i == MT - 1 ? a7[0] : af[i]);
       }
       W4_FENCE();
@@ -638,16 +647,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     if constexpr (LOAD2) select(kt + 2);
     // ---------------- block 2: MFMA(k-step 1) || DMA of tile kt+2 || reads of tile kt+1, k-step 0
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      if constexpr (LOAD2 && !(ABL & 1)) dma(kt & 1, g);
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (LOAD2 && !(ABL & 1)) {
+        dma(kt & 1, g);
+        if (g + NG < ND) dma(kt & 1, g + NG);
+      }
       if constexpr (MORE && !(ABL & 2)) {
-        if (g < 8) wf[0][g] = frag(sn, b_off[0], g);
-        if (g >= 2 && (g & 1) == 0) af[g / 2 - 1] = frag(sn, a_off[0], g / 2 - 1);
-        if (g == 9) a7[0] = frag(sn, a_off[0], MT - 1);
+        if (g < NT) wf[0][g] = frag(sn, b_off[0], g);
+        if (g >= 1 && (g * 4) % NT == 0 && g * 4 / NT - 1 <= MT - 2) af[g * 4 / NT - 1] = frag(sn, a_off[0], g * 4 / NT - 1);
+        if (g == LAST_A) a7[0] = frag(sn, a_off[0], MT - 1);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int t = g * 4 + q, i = t >> 3, j = t & 7;
+        const int t = g * 4 + q, i = t / NT, j = t % NT;
         mfma_tied(acc[i][j], wf[1][j], i == MT - 1 ? a7[1] : af[i]);
       }
       W4_FENCE();
@@ -669,8 +681,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
   for (int i = 0; i < MT; ++i)
-    asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]),
-                      "+a"(acc[i][4]), "+a"(acc[i][5]), "+a"(acc[i][6]), "+a"(acc[i][7]));
+#pragma unroll
+    for (int j = 0; j < NT; j += 4)
+      asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1]), "+a"(acc[i][j + 2]), "+a"(acc[i][j + 3]));
 #undef W4_FENCE
 #undef W4_BARRIER
 
@@ -720,12 +733,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   }
 }
 
-template <int ABL>
+template <int NT, int ABL>
 int launch_w4(GemmArgs& a, hipStream_t s) {
-  constexpr int LDS = 2 * (256 + 256) * ROW_BYTES;
+  constexpr int LDS = 2 * (256 + 32 * NT) * ROW_BYTES;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -733,7 +746,7 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<ABL>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -784,20 +797,23 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
                       (int64_t)a.M * a.lda2 < (1ll << 31) && (int64_t)a.N * a.ldw2 < (1ll << 31);
   if constexpr (BM == 256 && BN == 256) {
     if (!fits32 && (g_variant == 2 || (g_variant >= 0x20 && g_variant < 0x30))) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
-    if (g_variant == 2) return launch_w4<0>(a, s);
+    if (g_variant == 2) return launch_w4<8, 0>(a, s);
     // auto: the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and
     // epilogue (one workgroup per CU, nothing to overlap them with): measured crossover K ~ 3072-4096
-    if (g_variant == 3) {
-      if (fits32 && a.K + a.K2 >= 4096) return launch_w4<0>(a, s);
+    if (g_variant == 3 || g_variant == 4) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
+      if (fits32 && a.K + a.K2 >= 4096) return launch_w4<8, 0>(a, s);
       return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
     }
-    if (g_variant == 0x21) return launch_w4<1>(a, s);     // timing-only ablations (wrong results)
-    if (g_variant == 0x22) return launch_w4<2>(a, s);
-    if (g_variant == 0x24) return launch_w4<4>(a, s);
-    if (g_variant == 0x27) return launch_w4<7>(a, s);
-    if (g_variant == 0x28) return launch_w4<8>(a, s);
+    if (g_variant == 0x21) return launch_w4<8, 1>(a, s);     // timing-only ablations (wrong results)
+    if (g_variant == 0x22) return launch_w4<8, 2>(a, s);
+    if (g_variant == 0x24) return launch_w4<8, 4>(a, s);
+    if (g_variant == 0x27) return launch_w4<8, 7>(a, s);
+    if (g_variant == 0x28) return launch_w4<8, 8>(a, s);
   } else {
-    if (g_variant == 2 || g_variant == 3 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+    if constexpr (BM == 256 && BN == 128) {
+      if ((g_variant == 2 || g_variant == 3) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
+    }
+    if (g_variant == 2 || g_variant == 3 || g_variant == 4 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
   }
   if (g_variant == 1 || (g_variant == 0 && a.act == VLB_ACT_SWIGLU_PAIR)) {
     return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);

@@ -18,6 +18,9 @@ def main():
     variants = [int(v, 0) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,4,5".split(","))]
     shapes = [("qkv", 10240, 6144, 4096), ("o", 10240, 4096, 4096), ("gate_up", 10240, 28672, 4096),
               ("down", 10240, 4096, 14336), ("sq8192", 8192, 8192, 8192), ("vit_fc1", 34620, 4096, 1024)]
+    if os.environ.get("VLB_SHAPES") == "lora":          # the LoRA batch (M = 5861 packed rows): every GEMM has a re-cut tail
+        shapes = [("qkv", 5861, 6144, 4096), ("o", 5861, 4096, 4096), ("gate_up", 5861, 28672, 4096), ("down", 5861, 4096, 14336),
+                  ("d_gu", 5861, 4096, 28672), ("d_down", 5861, 14336, 4096)]
     for name, M, N, K in shapes:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
