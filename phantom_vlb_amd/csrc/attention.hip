@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   constexpr int QT_BYTES = BQ * ROWB;                              // 8 KB
   constexpr int G_BASE = 2 * BK_KEYS * ROWB;                       // per-group region starts here
   constexpr int G_QT = 0;                                          // [2][Q tile | dO tile] = 32 KB
-  constexpr int G_T = 4 * QT_BYTES;                                // dS^T image [128 keys][32 q] bf16 = 8 KB
+  constexpr int G_T = 4 * QT_BYTES;                                // dS^T image [128 keys][32 q] bf16 = 8 KB (chunk-swizzled)
   constexpr int G_L = G_T + BK_KEYS * 64;                          // [2][lse 32 | delta 32] f32 = 512 B
   constexpr int G_BYTES = G_L + 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -449,9 +449,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
     const int r = 8 * h + 4 * e + tq;
     kt_rd[e] = r * ROWB + (((4 * w4 + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
   }
-  int t_rd[2];
+  // dS^T image rows are 64 bytes (8 chunks of 8 B); chunk c of row R sits at c ^ ((R>>2)&7) so that neither the
+  // 8-byte writes (32 consecutive rows, one chunk) nor the transposed reads (4 rows x 8 chunks) collide on banks.
+  // Row R = 16s + 8h + 4e + tq  ->  (R>>2)&7 = 4(s&1) + 2h + e: two offsets per e, picked by the parity of s.
+  int t_rd[2][2];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) t_rd[e] = (8 * h + 4 * e + tq) * 64 + (16 * g1 + 4 * tp) * 2;
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int sp1 = 0; sp1 < 2; ++sp1)
+      t_rd[e][sp1] = (8 * h + 4 * e + tq) * 64 + (((4 * g1 + tp) ^ (4 * sp1 + 2 * h + e)) << 3);
 
   const float c2 = p.scale * 1.44269504088896341f;
   const int key = k0 + krow;
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
         bf16x4 t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
-        *reinterpret_cast<bf16x4*>(gsm + G_T + krow * 64 + (8 * g + 4 * h) * 2) = t;
+        *reinterpret_cast<bf16x4*>(gsm + G_T + krow * 64 + (((2 * g + h) ^ ((krow >> 2) & 7)) << 3)) = t;
       }
       // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
 #pragma unroll
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
           const int s = 4 * sh + s4;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            ta[s4][e] = tr_read_asm(gsm + G_T + t_rd[e] + 16 * s * 64);
+            ta[s4][e] = tr_read_asm(gsm + G_T + t_rd[e][s & 1] + 16 * s * 64);
             tk[s4][e] = tr_read_asm(smem + K_OFF + kt_rd[e] + 16 * s * ROWB);
           }
         }
