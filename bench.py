@@ -120,10 +120,10 @@ def main():
     opt, sch = m.configure_optimizers()
     opt, sch = opt[0], sch[0]["scheduler"]
     if use_dist:
-        from phantom_vlb_amd.parallel import attach_data_parallel, broadcast_parameters
+        from phantom_vlb_amd.parallel import attach_data_parallel, sync_module_states
         red = attach_data_parallel(m, opt)
         red.force = True                      # all-reduce even at world size 1 (rehearsal)
-        broadcast_parameters([m.flat.master, m.flat.compute])
+        sync_module_states(m)                 # rank 0's trainables everywhere + derived layouts rebuilt
     g = m.geometry
     batch = synthetic_batch(g, B, seed=1234 + rank, device=dev)
     # pixels / targets / weights are resident in HBM; the ids and padvals (20 KB) stay on the host, as a

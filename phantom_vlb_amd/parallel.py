@@ -142,6 +142,22 @@ def broadcast_parameters(tensors, src: int = 0, group=None):
             dist.broadcast(t, src=src, group=group)
 
 
+def sync_module_states(module, src: int = 0, group=None):
+    """Broadcast the trainable masters from rank `src` and rebuild everything derived from them on this rank:
+    the bf16 compute copies and (LoRA) the transposed / padded adapter layouts the kernels read."""
+    flat = getattr(module, "flat", None)
+    if flat is not None:
+        broadcast_parameters([flat.master], src, group)
+        flat.compute.copy_(flat.master)
+    else:
+        broadcast_parameters(module.parameters(), src, group)
+        for n, t in module.head.master.items():
+            module.head.compute[n].copy_(t)
+    lora = getattr(module, "lora", None)
+    if lora is not None:
+        lora.refresh(from_master=flat is None)
+
+
 class ShardedLayerStore:
     """1/world shard of every layer's flat weights + double-buffered, prefetched all-gather."""
 

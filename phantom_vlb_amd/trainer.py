@@ -136,10 +136,10 @@ class Trainer:
         opts, scheds = model.configure_optimizers()
         opt, sched = opts[0], scheds[0]["scheduler"]
         if self.world > 1:
-            from .parallel import attach_data_parallel, broadcast_parameters, init_distributed
+            from .parallel import attach_data_parallel, init_distributed, sync_module_states
             init_distributed()
             attach_data_parallel(model, opt)
-            broadcast_parameters(model.parameters())
+            sync_module_states(model)
         if ckpt_path:
             self.global_step = load_trainable_checkpoint(model, ckpt_path)
         try:
