@@ -310,6 +310,7 @@ constexpr int BK_KEYS = 128;   // keys per workgroup
 constexpr int BQ = 32;         // queries per inner block
 
 int g_attn_ablate = 0;
+int g_attn_split_dq = 1;      // 1: dQ in its own register-accumulating pass (default), 0: fp32 atomics from the dK/dV kernel
 struct AttnBwdArgs {
   const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
   const float* lse; const float* delta; const uint8_t* mask; const int* cu;
@@ -318,6 +319,7 @@ struct AttnBwdArgs {
   int B, S, Hq, Hkv;
   float scale;
   int ablate;      // timing-only experiments (wrong results): bit0 skip dQ atomics, bit1 skip the whole dQ phase
+  int split_dq;    // dQ is computed by attn_bwd_dq_kernel: this kernel only produces dK / dV
 };
 
 __device__ __forceinline__ int sw2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
@@ -505,13 +507,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
           dsb[r >> 3][r & 7] = (bf16)ds;
         }
       }
-      // ---- dS^T image: row = key (krow), cols q = 8g + 4h + {0..3}  (8-byte stores)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 t;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
-        *reinterpret_cast<bf16x4*>(gsm + G_T + krow * 64 + (((2 * g + h) ^ ((krow >> 2) & 7)) << 3)) = t;
+      if (!p.split_dq) {
+        // ---- dS^T image: row = key (krow), cols q = 8g + 4h + {0..3}  (8-byte stores)
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 t;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = dsb[g >> 1][(g & 1) * 4 + e];
+          *reinterpret_cast<bf16x4*>(gsm + G_T + krow * 64 + (((2 * g + h) ^ ((krow >> 2) & 7)) << 3)) = t;
+        }
       }
       // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (contraction over the 32 queries, 2 k-steps)
 #pragma unroll
@@ -533,9 +537,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       }
     }
     // raw barrier: __syncthreads() would add vmcnt(0) and drain the in-flight DMA and atomics
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // dS^T images complete
-    if (active && !(p.ablate & 2)) {
+    if (!p.split_dq) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // dS^T images complete
+    }
+    if (p.split_dq) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next Q/dO tile landed
+    } else if (active && !(p.ablate & 2)) {
       // ---- dQ[:, 32*w4 .. +32] = dS . K  over the workgroup's 128 keys (8 k-steps of 16 keys)
       f32x16 dq;
 #pragma unroll
@@ -609,6 +617,189 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// dQ in its own pass, shaped like the forward kernel: a workgroup owns 128 query rows of one q-head and
+// sweeps the key tiles, so dQ accumulates in registers - no fp32 atomics, no scratch buffer, and a fixed
+// summation order (bit-reproducible).  Per 64-key tile a wave recomputes S^T = K.Q^T and dP^T = V.dO^T
+// (query on the lane, as in the forward), forms dS^T = P^T.(dP^T - delta).scale in registers, and uses
+// those accumulators directly as the B operand of dQ^T += K^T.dS^T; K^T fragments are transposed reads of
+// the same row-major K tile (dual-use swizzle sw2, also conflict-free for the row reads).
+// -------------------------------------------------------------------------------------------------
+struct AttnDqArgs {
+  const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
+  const float* lse; const float* delta; const uint8_t* mask; const int* cu;
+  bf16* dq;
+  int ldq, ldk, ldv, lddo, lddq;
+  int B, S, Hq, Hkv;
+  float scale;
+};
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnDqArgs p) {
+  constexpr int D = 128, ROWB = 256, TILE = KV * ROWB, KS = 8, DT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.S + QB - 1) / QB;
+  const int qb = CAUSAL ? (nqb - 1 - blockIdx.x) : blockIdx.x;   // heavy (late) causal blocks first
+  const int hq = blockIdx.y, b = blockIdx.z;
+  const int hkv = hq / (p.Hq / p.Hkv);
+  const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
+  const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
+  if (qb * QB >= Sb) return;
+  const int q0 = qb * QB + wave * QW;
+  const int ql = lane & 31, h = lane >> 5;
+  const int qrow = q0 + ql;
+  const int qr = min(qrow, Sb - 1);
+
+  // Q and dO fragments (B operands): lane holds X[q][16ks + 8h + j]
+  bf16x8 qf[KS], dof[KS];
+  {
+    const bf16* qp = p.q + (row0 + qr) * p.ldq + hq * D + 8 * h;
+    const bf16* dp = p.dout + (row0 + qr) * p.lddo + hq * D + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dp + 16 * ks);
+    }
+  }
+  const float lse_q = p.lse[((int64_t)b * p.Hq + hq) * p.S + qr];
+  const float delta_q = p.delta[((int64_t)b * p.Hq + hq) * p.S + qr];
+  const float c2 = p.scale * 1.44269504088896341f;
+  // a fully masked row has lse = -inf: make every probability underflow to 0 instead of inf
+  const float lse2 = (lse_q > -1e37f) ? lse_q * 1.44269504088896341f : 1e37f;
+
+  f32x16 dqt[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
+
+  const int q_hi = min(qb * QB + QB, Sb) - 1;
+  const int ntiles = CAUSAL ? (q_hi / KV + 1) : (Sb + KV - 1) / KV;
+  const bf16* kbase = p.k + row0 * p.ldk + hkv * D;
+  const bf16* vbase = p.v + row0 * p.ldv + hkv * D;
+
+  const int sr = lane >> 4, sp = lane & 15;       // 4 rows x 16 chunks per wave-instruction
+  auto stage = [&](int buf, int t) {
+    char* kb = smem + buf * 2 * TILE; char* vb = kb + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (4 * i + wave) * 4 + sr;
+      const int key = min(t * KV + r, Sb - 1);
+      glds16(kbase + (int64_t)key * p.ldk + (sp ^ sw2(r)) * 8, kb + (4 * i + wave) * 1024);
+      glds16(vbase + (int64_t)key * p.ldv + (sp ^ sw2(r)) * 8, vb + (4 * i + wave) * 1024);
+    }
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int row_rd[KS];                                   // row reads (A operand of the score MFMAs): key = 32s + ql
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) row_rd[ks] = ql * ROWB + (((2 * ks + h) ^ sw2(ql)) << 4);
+  int tr_rd[DT][2];                                 // transposed reads of K: keys 4h + tq (+8), 32 columns of block dt
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 4 * h + tq + 8 * e;             // + 32s + 16s2: multiples of 16 leave sw2 unchanged
+      tr_rd[dt][e] = r * ROWB + (((4 * dt + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
+    }
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+    const char* kb = smem + cur * 2 * TILE; const char* vb = kb + TILE;
+    const int key0 = t * KV;
+    const bool active = !CAUSAL || (key0 <= q0 + QW - 1);
+    if (active) {
+      f32x16 st[2], dp[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[s][r] = 0.f; dp[s][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row_rd[ks] + 32 * s * ROWB);
+          st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[s], 0, 0, 0);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + row_rd[ks] + 32 * s * ROWB);
+          dp[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[s], 0, 0, 0);
+        }
+      }
+      unsigned long long kvalid;
+      {
+        const int key = key0 + lane;
+        bool ok = key < Sb;
+        if (ok && p.mask) ok = p.mask[row0 + key] != 0;
+        kvalid = __ballot(ok);
+      }
+      const bool diag = CAUSAL && (key0 + KV - 1 > q0);
+      const bool partial = diag || (kvalid != ~0ull);
+      if (partial) {
+        const unsigned lo = (unsigned)(kvalid >> (4 * h)), hi = (unsigned)(kvalid >> (32 + 4 * h));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned word = s ? hi : lo;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kb2 = (r & 3) + 8 * (r >> 2);
+            bool ok = (word >> kb2) & 1u;
+            if (CAUSAL) ok = ok && (key0 + 32 * s + 4 * h + kb2 <= qrow);
+            st[s][r] = ok ? st[s][r] : NEG;
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      // dS^T = P^T (dP^T - delta) scale, P^T = exp2(S^T c2 - lse2); masked entries underflow to exactly 0
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(st[s][r] * c2 - lse2);
+          st[s][r] = pv * (dp[s][r] - delta_q) * p.scale;
+        }
+      // dQ^T += K^T . dS^T ; dS^T fragment of k-step (s, s2) = bf16(st[s][8 s2 .. 8 s2 + 7])
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 df;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) df[j] = (bf16)st[s][8 * s2 + j];
+          const int roff = (32 * s + 16 * s2) * ROWB;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(kb + tr_rd[dt][0] + roff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(kb + tr_rd[dt][1] + roff));
+            dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(lo, hi), df, dqt[dt], 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (qrow < Sb) {
+    bf16* op = p.dq + (row0 + qrow) * p.lddq + hq * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)dqt[dt][4 * g + e];
+        *reinterpret_cast<bf16x4*>(op + 32 * dt + 8 * g + 4 * h) = o;
+      }
+  }
+}
+
 // dq (bf16, strided) = dq_acc (fp32 [B*S, Hq*128])
 __global__ void dq_convert_kernel(const float* __restrict__ acc, bf16* __restrict__ dq, int lddq, int width, int64_t total) {
   const int cpr = width >> 3;
@@ -641,10 +832,13 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((th + 15) / 16)), dim3(256), 0, st, (const bf16*)out, ldo,
                      (const bf16*)dout, lddo, delta, S, Hq, B, cu_rows, th);
   VLB_LAUNCH_CHECK();
-  hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
-  if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+  const int split = g_attn_split_dq;
+  if (!split) {
+    hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
+    if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+  }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
-                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale, g_attn_ablate};
+                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale, g_attn_ablate, split};
   constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
   static bool configured = false;
   if (!configured) {
@@ -657,6 +851,23 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
   else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
   VLB_LAUNCH_CHECK();
+  if (split) {
+    AttnDqArgs d{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
+                 (bf16*)dq, ldq, ldk, ldv, lddo, lddq, B, S, Hq, Hkv, scale};
+    constexpr int LDS_DQ = 2 * 2 * KV * 256;       // 64 KB: two workgroups per CU
+    static bool configured_dq = false;
+    if (!configured_dq) {
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+      if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dq)"); return VLB_ERR_LAUNCH; }
+      configured_dq = true;
+    }
+    dim3 gq((S + QB - 1) / QB, Hq, B);
+    if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), LDS_DQ, st, d);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), LDS_DQ, st, d);
+    VLB_LAUNCH_CHECK();
+    return VLB_OK;
+  }
   const int64_t total = rows * (Hq * D / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dq_convert_kernel, dim3(blocks), dim3(256), 0, st, dq_acc, (bf16*)dq, lddq, Hq * D, total);
@@ -665,4 +876,4 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
 }
 
 // tuning hook (not part of the stable ABI): timing-only ablations of the attention backward kernel
-extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits; }
+extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits & 3; g_attn_split_dq = (bits & 4) ? 0 : 1; }   // bit2: legacy atomic dQ

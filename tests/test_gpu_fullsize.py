@@ -176,6 +176,28 @@ def test_step_is_deterministic(dev):
     assert l1 == l2 and torch.equal(g1, g2)
 
 
+def test_lora_step_is_deterministic(dev):
+    """LoRA step (dropout on): forward, attention backward (dQ in its own register-accumulating pass, no
+    atomics), skinny wgrads and the head are all fixed-order -> two runs from the same state are bit-identical."""
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.synthetic import synthetic_batch
+    cfg = VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=True, lora_r=16, lora_alpha=32,
+                             lora_dropout=0.1, dropout_rate=0.0, num_target=128, l2_lambda=1e-3, lr=1e-3, betas=[0.9, 0.999],
+                             eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000,
+                             geometry="mini")
+    m = VLBLitModule(cfg)
+    m.configure_model()
+    m.configure_optimizers()
+    batch = synthetic_batch(m.geometry, 3, seed=2)
+    out = []
+    for _ in range(2):
+        m.lora.step = 0                           # same dropout seeds for both runs
+        loss = float(m.training_step(batch))
+        out.append((loss, m.flat.grad.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+
+
 def test_7b_step_packed_equals_dense(dev):
     """BASELINE configs[1] at full size (7B frozen backbone, 2048 targets, max_len 2048, B=2): the
     unpadded row layout gives the SAME loss and head gradients, bit for bit, as the dense layout."""

@@ -53,10 +53,8 @@ def test_attention_packed_equals_dense(dev, B, S, Hq, Hkv, lens):
     assert torch.equal(out_p, _pack(out_d.view(B, S, -1), lens))
     for b, n in enumerate(lens):
         assert torch.equal(lse_p[b, :, :n], lse_d[b, :, :n])
-    got, want = dqkv_p.float(), _pack(dqkv_d.view(B, S, -1), lens).float()
-    # dk/dv: same reduction order -> identical; dq is accumulated with fp32 atomics (order-dependent)
-    assert torch.equal(got[:, qd:], want[:, qd:])
-    assert (got[:, :qd] - want[:, :qd]).abs().max() <= 2e-2 * want[:, :qd].abs().max()
+    # dq, dk, dv: every reduction runs in a fixed order relative to the clip's first row -> identical
+    assert torch.equal(dqkv_p, _pack(dqkv_d.view(B, S, -1), lens))
 
 
 def test_rope_and_splice_packed(dev):

@@ -33,11 +33,10 @@ print(f"fwd  {t*1e6:8.1f} us  {fwd_flops/t/1e12:6.1f} TF/s")
 modes = [0]
 if hasattr(lib, "vlb_attn_set_ablation"):
     lib.vlb_attn_set_ablation.argtypes = [ctypes.c_int]; lib.vlb_attn_set_ablation.restype = None
-    modes = [0, 1, 2]
+    modes = [0, 4, 5, 6]        # 0: split dQ pass (default); 4: legacy atomic dQ; 5/6: its timing-only ablations
 for m in modes:
-    if m:
-        lib.vlb_attn_set_ablation(m)
+    lib.vlb_attn_set_ablation(m) if len(modes) > 1 else None
     t = timeit(lambda: ops.attention_bwd(qkv, qd, kd, out, dout, lse, mask, B, S, Hq, Hkv, D, True, D ** -0.5))
-    print(f"bwd ablate={m} {t*1e6:8.1f} us  {2.5*fwd_flops/t/1e12:6.1f} TF/s")
+    print(f"bwd mode={m} {t*1e6:8.1f} us  {2.5*fwd_flops/t/1e12:6.1f} TF/s")
 if len(modes) > 1:
     lib.vlb_attn_set_ablation(0)
