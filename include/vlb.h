@@ -84,7 +84,9 @@ int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void
                       float scale, const int* cu_rows, void* stream);
 
 /* Backward of the above. dq/dk/dv have the layout/strides of q/k/v.  delta: [B,Hq,S] fp32 workspace.
- * dq_acc: [rows,Hq,D] fp32 workspace (zeroed by the call).  total_rows = cu_rows[B] (host copy;
+ * Three launches: delta = rowsum(dout*out); dK/dV (key-block outer loop); dQ (query-block outer loop,
+ * accumulated in registers: no atomics, reproducible).  dq_acc: unused by the default path, may be NULL
+ * (fp32 [rows,Hq,D] scratch of the selectable atomic-dQ variant).  total_rows = cu_rows[B] (host copy;
  * ignored when cu_rows == NULL, where rows = B*S). */
 int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
                       int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,

@@ -820,7 +820,8 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
                                  int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B,
                                  int S, int Hq, int Hkv, int D, int causal, float scale, const int* cu_rows, int total_rows,
                                  void* stream) {
-  VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta && dq_acc, "attention_bwd: null operand");
+  VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "attention_bwd: null operand");
+  VLB_REQUIRE(g_attn_split_dq || dq_acc, "attention_bwd: the atomic dQ variant needs the dq_acc workspace");
   VLB_REQUIRE(D == 128, "attention_bwd: head dim %d unsupported (only 128: the decoder)", D);
   VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
   VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&

@@ -271,7 +271,6 @@ class LoraState:
         M = self.x_last.shape[0]
         dx = ops.rmsnorm_bwd(self.x_last, w.final_norm, dhidden, g.rms_eps)
         delta = torch.empty(B, g.heads, S, dtype=torch.float32, device=self.dev)
-        dq_acc = torch.empty(M, qd, dtype=torch.float32, device=self.dev)
         for li in range(g.layers - 1, -1, -1):
             lw, sv = backbone.layer_weights(li, transposed=True, direction=-1), self.saved[li]
             sd = sv["seeds"]
@@ -282,7 +281,7 @@ class LoraState:
             d_a = self._group_backward(li, "o", dx2, sv["a"], sv["t_o"], sd[3:4], lw["wo_t"], True)
             qkv = sv["qkv"]
             dqkv = ops.attention_bwd(qkv, qd, kd, sv["a"], d_a, sv["lse"], self.key_mask, B, S, g.heads, g.kv_heads,
-                                     g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta, dq_acc=dq_acc)
+                                     g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta)
             ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
             need_dx = li > 0                # embeddings / connector are frozen: nothing upstream of layer 0 trains
             d_h1 = self._group_backward(li, "qkv", dqkv, sv["h1"], sv["t_qkv"], sd[0:3], lw["wqkv_t"], need_dx)

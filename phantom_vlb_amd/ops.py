@@ -161,15 +161,13 @@ def attention_bwd(qkv, qd, kd, out, dout, lse, key_mask, B, S, Hq, Hkv, D, causa
     assert qkv.shape[0] == rows and dout.shape[0] == rows
     if delta is None:
         delta = torch.empty(B, Hq, S, dtype=torch.float32, device=qkv.device)
-    if dq_acc is None:
-        dq_acc = torch.empty(rows, qd, dtype=torch.float32, device=qkv.device)
-    assert delta.numel() >= B * Hq * S and dq_acc.numel() >= rows * qd
+    assert delta.numel() >= B * Hq * S and (dq_acc is None or dq_acc.numel() >= rows * qd)
     dqkv = torch.empty_like(qkv)
     check(lib.vlb_attention_bwd(qkv.data_ptr(), qkv.stride(0), qkv[:, qd:].data_ptr(), qkv.stride(0),
                                 qkv[:, qd + kd:].data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0),
                                 dout.data_ptr(), dout.stride(0), lse.data_ptr(), _p(key_mask),
                                 dqkv.data_ptr(), dqkv.stride(0), dqkv[:, qd:].data_ptr(), dqkv.stride(0),
-                                dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), dq_acc.data_ptr(),
+                                dqkv[:, qd + kd:].data_ptr(), dqkv.stride(0), delta.data_ptr(), _p(dq_acc),
                                 B, S, Hq, Hkv, D, 1 if causal else 0, float(scale), _p(cu), rows, _stream()),
           "vlb_attention_bwd")
     return dqkv

@@ -36,7 +36,8 @@ if hasattr(lib, "vlb_attn_set_ablation"):
     modes = [0, 4, 5, 6]        # 0: split dQ pass (default); 4: legacy atomic dQ; 5/6: its timing-only ablations
 for m in modes:
     lib.vlb_attn_set_ablation(m) if len(modes) > 1 else None
-    t = timeit(lambda: ops.attention_bwd(qkv, qd, kd, out, dout, lse, mask, B, S, Hq, Hkv, D, True, D ** -0.5))
+    acc = torch.empty(B * S, qd, dtype=torch.float32, device=dev) if m & 4 else None
+    t = timeit(lambda: ops.attention_bwd(qkv, qd, kd, out, dout, lse, mask, B, S, Hq, Hkv, D, True, D ** -0.5, dq_acc=acc))
     print(f"bwd mode={m} {t*1e6:8.1f} us  {2.5*fwd_flops/t/1e12:6.1f} TF/s")
 if len(modes) > 1:
     lib.vlb_attn_set_ablation(0)
