@@ -99,6 +99,11 @@ def main():
         backend = os.environ.get("VLB_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from phantom_vlb_amd import ops
+    if os.environ.get("VLB_GEMM_VARIANT"):        # A/B of GEMM kernel selection on the real step (tuning hook)
+        import ctypes
+        from phantom_vlb_amd._lib import lib
+        lib.vlb_gemm_set_variant.argtypes, lib.vlb_gemm_set_variant.restype = [ctypes.c_int, ctypes.c_int], None
+        lib.vlb_gemm_set_variant(int(os.environ["VLB_GEMM_VARIANT"], 0), 0)
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
 

@@ -515,17 +515,18 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
 }
 
 // NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
-// of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.
-template <int NT = 8, int ABL = 0>
+// of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.  MT = 6: 192-row tiles (wave
+// block 96 rows), picked by the host when they quantise the row count into fewer, fuller waves of tiles.
+template <int NT = 8, int ABL = 0, int MT = 8>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
-  constexpr int MT = 8, TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
+  constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
   constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
   constexpr int LAST_A = NG / 2 + 1;                   // group in which the double-slotted last A fragment is fetched
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int A_LD = BM / 32, B_LD = BN / 32;       // LDS-DMA instructions per thread per tile (32 rows each)
   constexpr int ND = A_LD + B_LD;
-  static_assert(NT == 8 || NT == 4, "wave block 128x128 or 128x64");
+  static_assert((NT == 8 || NT == 4) && (MT == 8 || MT == 6), "wave block 128|96 rows x 128|64 columns");
   static_assert(ND <= 2 * NG && (NT - 1) < NG && (2 * (MT - 2) + 2) * NT / 8 < NG, "schedule does not fit the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -599,8 +600,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     select(1);
 #pragma unroll
     for (int i = 0; i < A_LD + B_LD; ++i) dma(1, i);
-    if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed; tile 1 may still fly
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");      // tile 0 landed; tile 1 (ND younger loads) may still fly
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -733,12 +733,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   }
 }
 
-template <int NT, int ABL>
+template <int NT, int ABL, int MT = 8>
 int launch_w4(GemmArgs& a, hipStream_t s) {
-  constexpr int LDS = 2 * (256 + 32 * NT) * ROW_BYTES;
+  constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -746,13 +746,14 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
 
 int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong wave groups, 2: four-wave 128x128 blocks,
-                        // 3 (default): four-wave kernel for long K (>= 4096), ping-pong otherwise
+                        // 3 (default): four-wave kernel for long K (>= 4096), ping-pong otherwise, 192-row tiles
+                        // when the cost model prefers them; 5 (A/B): like 3 but always 192-row tiles for long K
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 
@@ -800,7 +801,7 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     if (g_variant == 2) return launch_w4<8, 0>(a, s);
     // auto: the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and
     // epilogue (one workgroup per CU, nothing to overlap them with): measured crossover K ~ 3072-4096
-    if (g_variant == 3 || g_variant == 4) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
+    if (g_variant == 3 || g_variant == 4 || g_variant == 5) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
       if (fits32 && a.K + a.K2 >= 4096) return launch_w4<8, 0>(a, s);
       return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
     }
@@ -811,9 +812,9 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     if (g_variant == 0x28) return launch_w4<8, 8>(a, s);
   } else {
     if constexpr (BM == 256 && BN == 128) {
-      if ((g_variant == 2 || g_variant == 3) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
+      if ((g_variant == 2 || g_variant == 3 || g_variant == 5) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
     }
-    if (g_variant == 2 || g_variant == 3 || g_variant == 4 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+    if (g_variant == 2 || g_variant == 3 || g_variant == 4 || g_variant == 5 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
   }
   if (g_variant == 1 || (g_variant == 0 && a.act == VLB_ACT_SWIGLU_PAIR)) {
     return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
@@ -907,6 +908,33 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
     // half as long.  Both launches walk the same tile order (map_tile), so the cut can be at any tile.
     const int cus = 256, tn = N / 256, tm = (M + 255) / 256;
     const int tiles = tm * tn, rem = tiles % cus;
+    // Row quantisation: 192-row tiles (four-wave kernel only) when they cut the row count into fewer, fuller
+    // waves - e.g. M=5861, N=4096: 23x16 = 368 tiles of 256 rows cost (1 + 0.62 tail) x 256 = 415 row-units,
+    // 31x16 = 496 tiles of 192 rows cost 2 x 192 = 384.  Cost = waves x tile rows; a re-cut partial wave = 0.62.
+    {
+      const bool fits32 = (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) &&
+                          (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
+      auto waves = [&](int t, bool& split) {
+        const int full = t / cus, r = t % cus;
+        split = g_tail_split && t > cus && r != 0 && r <= cus * 5 / 8;
+        return (double)full + (r == 0 ? 0.0 : (split ? 0.62 : 1.0));
+      };
+      bool s256, s192;
+      const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
+      const double c256 = waves(tiles, s256) * 256.0, c192 = waves(tiles192, s192) * 192.0 * 1.02;   // 2 %: smaller tile
+      if ((g_variant == 3 || g_variant == 5) && g_force_tile == 0 && fits32 && K + K2 >= 4096 && tiles > cus &&
+          (g_variant == 5 || c192 < 0.97 * c256)) {
+        GemmArgs hi = a;
+        hi.tiles_m = tm192; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
+        const int rem192 = tiles192 % cus;
+        hi.grid = s192 ? tiles192 - rem192 : tiles192;
+        int rc = launch_w4<8, 0, 6>(hi, s);
+        if (rc != VLB_OK || !s192) return rc;
+        GemmArgs lo = hi;
+        lo.tile0 = tiles192 - rem192; lo.split_n = 2; lo.grid = 2 * rem192;
+        return launch_w4<4, 0, 6>(lo, s);
+      }
+    }
     if (g_tail_split && tiles > cus && rem != 0 && rem <= cus * 5 / 8) {
       GemmArgs hi = a, lo = a;
       hi.tiles_m = lo.tiles_m = tm;

@@ -44,6 +44,8 @@ def test_gemm_shapes(dev, M, N, K):
     (600, 256, 4096, 64),     # ... with the LoRA operand pair appended to the K loop
     (4500, 4096, 128, 0),     # 288 tiles = 1.125 waves -> tail split (ping-pong kernel + 256x128 halves)
     (4500, 4096, 4096, 64),   # tail split behind the four-wave kernel, second operand pair
+    (5861, 4096, 4096, 0),    # 368 tiles of 256 rows -> the cost model picks 192-row tiles (496 = 2 waves)
+    (3000, 6144, 4096, 64),   # 192-row tiles (16x24 = 384 tiles = 256 + 128 re-cut into 192x128 halves)
 ])
 def test_gemm_long_k_and_tail_split(dev, M, N, K, K2):
     from phantom_vlb_amd import ops
