@@ -215,6 +215,14 @@ int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M
  * K % 64 == 0, dx 16-byte aligned with lddx % 8 == 0. */
 int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
                        const uint32_t* seeds_host, void* stream);
+/* dB^T and u in one pass over dY (LoRA backward of one projection, rank 16):
+ *   dW[16,K] (fp32) = alpha * G[:, :16]^T . X + beta * dW        (G = t, X = dY  ->  dB^T = t^T dY)
+ *   u[m, 0:16] (bf16, row stride ldu) = u_scale * X[m,:] . Bt^T    (Bt = B^T [16,K] bf16  ->  u = s dY B)
+ * ws as for vlb_wgrad_skinny; u_ws: fp32 [vlb_wgrad_u_ws_floats(M,K)] partials per 256-column block, summed
+ * in a fixed order.  K % 64 == 0.  Replaces a vlb_lora_down + vlb_wgrad_skinny pair (two sweeps over dY). */
+int64_t vlb_wgrad_u_ws_floats(int M, int K);
+int vlb_wgrad_skinny_u(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int K, float alpha,
+                       float beta, const void* Bt, float u_scale, void* u, int ldu, float* u_ws, void* stream);
 /* Rebuild derived adapter layouts after an optimiser step in ONE launch.  jobs: device array of n_jobs
  * records {const bf16* src; bf16* dst; int32 n; int32 n0; int32 ld; int32 pad} (32 bytes): rows
  * [n0, n0+256) of the transpose of the row-major [16, n] matrix `src` are written to dst[i*ld + 0..15]

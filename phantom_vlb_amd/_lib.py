@@ -48,6 +48,8 @@ SIGNATURES = {
     "vlb_head_ws_floats": [I, I, I, I],
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P, I, P],
+    "vlb_wgrad_u_ws_floats": [I, I],
+    "vlb_wgrad_skinny_u": [P, I, P, I, P, P, I, I, F, F, P, F, P, I, P, P],
     "vlb_transpose16_scatter": [P, I, P],
     "vlb_wgrad_splits": [I],
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
@@ -59,7 +61,7 @@ SIGNATURES = {
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
-_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64}
+_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64}
 
 
 class VlbError(RuntimeError):

@@ -213,13 +213,20 @@ __device__ __forceinline__ void glds16_l(const void* g, void* l) {
 // 32-byte pair slot swizzle of the X tile: rows r and r+8 and the 4 rows of a transposed read all differ
 __device__ __forceinline__ int xsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int G>
+// WITH_U (G = 1): the same pass over X also forms the block's slice of  u = X . Bt^T  (contraction over this
+// block's 256 columns): wave w multiplies its 64 columns of every 32-row tile by the matching 64 columns of
+// Bt [16, K] (row reads of the X image, MFMA rows = ranks), the four waves' partials meet in LDS and are stored as
+// upart[column block][row][16] fp32 - summed over column blocks by u_reduce_kernel.  This is LoRA backward's
+// u = s dy B riding on the dB^T = t^T dy pass, instead of a second sweep over dy.
+template <int G, bool WITH_U = false>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict__ Gm, int ldg, const bf16* __restrict__ X,
                                                          int ldx, float* __restrict__ ws, int M, int K,
-                                                         int rows_per_split, uint32_t thresh, Seeds seeds) {
+                                                         int rows_per_split, uint32_t thresh, Seeds seeds,
+                                                         const bf16* __restrict__ Bt = nullptr, float* __restrict__ upart = nullptr) {
   constexpr int XT = WG_STEP * WG_COLS * 2;          // 16 KB
   constexpr int GT = WG_STEP * 16 * G * 2;           // 1 KB per group
-  __shared__ __attribute__((aligned(16))) char smem[2 * (XT + GT)];
+  constexpr int UT = WITH_U ? 2 * 4 * 2 * 4 * 64 * 4 : 0;     // [parity][wave][row tile][reg][lane] fp32 = 16 KB
+  __shared__ __attribute__((aligned(16))) char smem[2 * (XT + GT) + UT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = blockIdx.x * WG_COLS;
@@ -232,6 +239,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // u = X . Bt^T: this wave's 64 columns = two k-steps of 32; Bt fragments stay in registers for the whole block
+  bf16x8 btf[2];
+  if constexpr (WITH_U) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = min(c0 + wave * 64 + 32 * ks + 8 * fq, K - 8);
+      btf[ks] = *reinterpret_cast<const bf16x8*>(Bt + (int64_t)fr * K + col);
+      if (c0 + wave * 64 + 32 * ks + 8 * fq >= K) btf[ks] = bf16x8{};
+    }
+  }
+  float* ured = reinterpret_cast<float*>(smem + 2 * (XT + GT));
 
   // staging: X piece i of this wave = rows 2*(4i+wave) + (lane>>5); 16-byte position pc = lane & 31
   auto stage = [&](int buf, int m0) {
@@ -304,8 +323,41 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
         acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], xm, acc[g][n], 0, 0, 0);
       }
     }
+    if constexpr (WITH_U) {
+      // row reads of the X image: source chunk c (8 columns) of row r sits at 16-byte position
+      // (((c>>1) ^ xsw(r)) << 1) | (c&1) of the row's 512 bytes
+      float* mine = ured + ((cur * 4 + wave) * 2) * 4 * 64;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 ua = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int r = 16 * t + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int c = wave * 8 + 4 * ks + fq;                 // 16-byte source chunk inside the 256-column tile
+          const int pc = (((c >> 1) ^ xsw(r)) << 1) | (c & 1);
+          const bf16x8 xr = *reinterpret_cast<const bf16x8*>(xb + r * 512 + pc * 16);
+          ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btf[ks], xr, ua, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[(t * 4 + e) * 64 + lane] = ua[e];
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (WITH_U) {
+      // sum the four waves' partials of this step (fixed order) and store [row][16 ranks]: 512 values, 2 per thread
+      const float* base = ured + cur * 4 * 2 * 4 * 64;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int idx = tid + 256 * q;                         // (t, e, lane)
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += base[w * 2 * 4 * 64 + idx];
+        const int l = idx & 63, e = (idx >> 6) & 3, t = idx >> 8;
+        const int row = m0 + 16 * t + (l & 15), rank = 4 * (l >> 4) + e;
+        if (row < r1) upart[((int64_t)blockIdx.x * M + row) * 16 + rank] = v;
+      }
+    }
   }
   // partial slab: lane owns column c0 + wave*64 + n*16 + fr of ranks 16g + 4fq + {0..3}
 #pragma unroll
@@ -348,6 +400,26 @@ __global__ __launch_bounds__(256) void transpose16_scatter_kernel(const ScatterJ
   bf16* d = j.dst + (int64_t)i * j.ld;
   *reinterpret_cast<bf16x8*>(d) = lo;
   *reinterpret_cast<bf16x8*>(d + 8) = hi;
+}
+
+// One launch for both fixed-order sums of the fused dB/u pass: blocks [0, wblocks) reduce the dW slabs (grid-stride),
+// the rest compute u[m][r] (bf16, row stride ldu) = scale * sum over column blocks of upart[block][m][r].
+__global__ void wgrad_u_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int splits, int64_t nk, float alpha,
+                                      float beta, int wblocks, const float* __restrict__ upart, bf16* __restrict__ u, int ldu,
+                                      int M, int nblk, float scale) {
+  if ((int)blockIdx.x < wblocks) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)wblocks * blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * nk + i];
+      dW[i] = alpha * s + (beta != 0.f ? beta * dW[i] : 0.f);
+    }
+    return;
+  }
+  const int64_t i = (int64_t)(blockIdx.x - wblocks) * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * 16) return;
+  float v = 0.f;
+  for (int b = 0; b < nblk; ++b) v += upart[(int64_t)b * M * 16 + i];
+  u[(i >> 4) * ldu + (i & 15)] = (bf16)(v * scale);
 }
 
 inline uint32_t lowbias32_host(uint32_t x) {
@@ -446,6 +518,32 @@ extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ld
 extern "C" int vlb_transpose16_scatter(const void* jobs, int n_jobs, void* stream) {
   VLB_REQUIRE(jobs && n_jobs > 0, "transpose16_scatter: empty job table");
   hipLaunchKernelGGL(transpose16_scatter_kernel, dim3(n_jobs), dim3(256), 0, as_stream(stream), (const ScatterJob*)jobs);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int64_t vlb_wgrad_u_ws_floats(int M, int K) { return (int64_t)((K + WG_COLS - 1) / WG_COLS) * M * 16; }
+
+extern "C" int vlb_wgrad_skinny_u(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int K,
+                                  float alpha, float beta, const void* Bt, float u_scale, void* u, int ldu, float* u_ws,
+                                  void* stream) {
+  VLB_REQUIRE(G && X && dW && ws && Bt && u && u_ws, "wgrad_skinny_u: null operand");
+  VLB_REQUIRE(M > 0 && K >= 64 && K % 64 == 0 && ldx % 8 == 0 && ldg % 8 == 0 && ldu >= 16,
+              "wgrad_skinny_u: bad shape M=%d K=%d", M, K);
+  VLB_REQUIRE((((uintptr_t)G | (uintptr_t)X | (uintptr_t)Bt) % 16) == 0, "wgrad_skinny_u: operands must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int splits = vlb_wgrad_splits(M);
+  const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
+  const Seeds sd = make_seeds(nullptr, 1, M, K);
+  dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps,
+                     0u, sd, (const bf16*)Bt, u_ws);
+  VLB_LAUNCH_CHECK();
+  const int64_t nk = (int64_t)16 * K;
+  int wblocks = (int)((nk + 255) / 256); if (wblocks > 1024) wblocks = 1024;
+  const int ublocks = (int)(((int64_t)M * 16 + 255) / 256);
+  hipLaunchKernelGGL(wgrad_u_reduce_kernel, dim3(wblocks + ublocks), dim3(256), 0, st, ws, dW, splits, nk, alpha, beta, wblocks,
+                     u_ws, (bf16*)u, ldu, M, (int)grid.x, u_scale);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

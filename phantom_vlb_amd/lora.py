@@ -49,6 +49,14 @@ def lora_dx_masked(u, At, dx, R, p, seeds):
                                  _seeds(seeds), _stream()), "vlb_lora_dx_masked")
 
 
+def wgrad_skinny_u(G, X, dW, ws, Bt, u_scale, u_out, u_ws, alpha=1.0, beta=0.0):
+    """dW [16,K] fp32 = alpha G[:, :16]^T X + beta dW  and  u_out[:, :16] = u_scale X Bt^T in one pass over X."""
+    M, K = X.shape
+    check(lib.vlb_wgrad_skinny_u(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), ws.data_ptr(), M, K,
+                                 alpha, beta, Bt.data_ptr(), u_scale, u_out.data_ptr(), u_out.stride(0), u_ws.data_ptr(),
+                                 _stream()), "vlb_wgrad_skinny_u")
+
+
 def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seeds=None):
     """dW [N,K] fp32 (contiguous) = alpha/(1-p) * G[:, :N]^T keep(X) + beta*dW; N in {16,32,48}."""
     M, K = X.shape
@@ -184,6 +192,7 @@ class LoraState:
             g, d = self.g, self.dev
             kmax = max(g.ff, g.dim, g.heads * g.head_dim)
             self._ws = dict(cap=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
+                            uws=torch.empty(lib.vlb_wgrad_u_ws_floats(M, kmax), dtype=torch.float32, device=d),
                             u_full=torch.zeros(M, PAD, dtype=BF16, device=d))
         self._ws["u"] = self._ws["u_full"][:M]
         return self._ws
@@ -246,10 +255,10 @@ class LoraState:
             n = self.out_dims[tname]
             pre = f"model.layers.{li}.{tname}"
             dyj = dy[:, col:col + n]
-            # u_j = s * dy_j . B_j   (B^T [r,out] is exactly the [R,K] operand of the skinny kernel)
-            lora_down(dyj, self.bt[f"{pre}.lora_B.weight"], 16, self.scale, 0.0, None, u[:, 16 * j:16 * j + 16])
-            # dB^T[r,out] = sum_m t[m,r] dy[m,out]      (t carries s and 1/(1-p))
-            wgrad_skinny(t[:, 16 * j:16 * j + 16], dyj, self.grads[f"{pre}.lora_B.weight"], ws["wg"], 16)
+            # one pass over dy_j: dB^T[r,out] = sum_m t[m,r] dy[m,out] (t carries s and 1/(1-p))  and
+            # u_j = s * dy_j . B_j for the dA / dx terms below
+            wgrad_skinny_u(t[:, 16 * j:16 * j + 16], dyj, self.grads[f"{pre}.lora_B.weight"], ws["wg"],
+                           self.bt[f"{pre}.lora_B.weight"], self.scale, u[:, 16 * j:16 * j + 16], ws["uws"])
             col += n
         # dA[r,in] = sum_m u[m,r] keep_g(x[m,in])/(1-p) for every projection of the group in one pass over x
         wgrad_skinny(u, x_in, self.grad_A[li][gname], ws["wg"], lay["R"], p=self.p, seeds=seeds)

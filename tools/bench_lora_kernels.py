@@ -49,3 +49,19 @@ for K, N, p in [(4096, 48, 0.1), (4096, 16, 0.1), (4096, 32, 0.1), (14336, 16, 0
     dt = timeit(lambda: wgrad_skinny(Gm, X, dW, ws, N, p=p, seeds=seeds3[:N // 16] if p > 0 else None))
     byt = M * K * 2 + M * N * 2 + N * K * 4
     print(f"wgrad      K={K:5d} N={N} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
+# dB^T + u fused (one pass over dy) vs the lora_down + wgrad pair
+from phantom_vlb_amd.lora import wgrad_skinny_u
+for K in (4096, 14336, 1024):
+    t_ = torch.randn(M, PAD, device=dev).to(BF)
+    dy = torch.randn(M, K, device=dev).to(BF)
+    Bt = (torch.randn(16, K, device=dev) * 0.02).to(BF)
+    dW = torch.zeros(16, K, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.vlb_wgrad_splits(M) * 48 * K, dtype=torch.float32, device=dev)
+    uws = torch.empty(lib.vlb_wgrad_u_ws_floats(M, K), dtype=torch.float32, device=dev)
+    u = torch.zeros(M, PAD, dtype=BF, device=dev)
+    def pair():
+        lora_down(dy, Bt, 16, 2.0, 0.0, None, u)
+        wgrad_skinny(t_, dy, dW, ws, 16)
+    ta = timeit(pair)
+    tb = timeit(lambda: wgrad_skinny_u(t_, dy, dW, ws, Bt, 2.0, u, uws))
+    print(f"dB+u      K={K:5d}: separate {ta*1e6:7.1f} us  fused {tb*1e6:7.1f} us", flush=True)
