@@ -376,6 +376,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
                                     float beta) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * nk + i];
     dW[i] = alpha * s + (beta != 0.f ? beta * dW[i] : 0.f);
   }
@@ -410,7 +411,8 @@ __global__ void wgrad_u_reduce_kernel(const float* __restrict__ ws, float* __res
   if ((int)blockIdx.x < wblocks) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)wblocks * blockDim.x) {
       float s = 0.f;
-      for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * nk + i];
+#pragma unroll 8
+      for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * nk + i];          // loads independent: 8 in flight
       dW[i] = alpha * s + (beta != 0.f ? beta * dW[i] : 0.f);
     }
     return;
@@ -418,6 +420,7 @@ __global__ void wgrad_u_reduce_kernel(const float* __restrict__ ws, float* __res
   const int64_t i = (int64_t)(blockIdx.x - wblocks) * blockDim.x + threadIdx.x;
   if (i >= (int64_t)M * 16) return;
   float v = 0.f;
+#pragma unroll 8
   for (int b = 0; b < nblk; ++b) v += upart[(int64_t)b * M * 16 + i];
   u[(i >> 4) * ldu + (i & 15)] = (bf16)(v * scale);
 }
