@@ -219,37 +219,42 @@ def test_attention_softmax_rescale_branch(dev):
 
 
 # ------------------------------------------------------------------ norms & element-wise
-def test_rmsnorm(dev):
+# dims walk every kernel path: register-cached rows (<= 512, <= 1024 for LayerNorm, <= 4096) and the generic loop
+@pytest.mark.parametrize("dim", [128, 512, 1024, 4096, 6144])
+def test_rmsnorm(dev, dim):
     from phantom_vlb_amd import ops
-    x, w = _r(37, 512, dev=dev, scale=2.0), (1 + 0.1 * torch.randn(512)).to(BF).to(dev)
+    x, w = _r(37, dim, dev=dev, scale=2.0), (1 + 0.1 * torch.randn(dim)).to(BF).to(dev)
     y = ops.rmsnorm(x, w, 1e-5)
     xf = x.float()
     ref = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
     assert rel_err(y, ref) < 8e-3
 
 
-def test_rmsnorm_bwd(dev):
+@pytest.mark.parametrize("dim", [512, 4096])
+def test_rmsnorm_bwd(dev, dim):
     from phantom_vlb_amd import ops
-    x, w, dy = _r(33, 512, dev=dev), (1 + 0.1 * torch.randn(512)).to(BF).to(dev), _r(33, 512, dev=dev, seed=3)
-    xin = _r(33, 512, dev=dev, seed=9)
+    x, w, dy = _r(33, dim, dev=dev), (1 + 0.1 * torch.randn(dim)).to(BF).to(dev), _r(33, dim, dev=dev, seed=3)
+    xin = _r(33, dim, dev=dev, seed=9)
     xr = x.float().cpu().requires_grad_(True)
     (w.float().cpu() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5)) * dy.float().cpu()).sum().backward()
     dx = ops.rmsnorm_bwd(x, w, dy, 1e-5, dx_in=xin)
     assert rel_err(dx, xr.grad + xin.float().cpu()) < 8e-3
 
 
-@pytest.mark.parametrize("act,res", [(0, False), (3, True)])
-def test_layernorm(dev, act, res):
+@pytest.mark.parametrize("act,res,dim", [(0, False, 128), (3, True, 128), (0, False, 1024), (3, True, 4096), (1, True, 5120)])
+def test_layernorm(dev, act, res, dim):
     from phantom_vlb_amd import ops
-    x = _r(50, 128, dev=dev, scale=3.0)
-    w, b = (1 + 0.1 * torch.randn(128)).to(BF).to(dev), (0.1 * torch.randn(128)).to(BF).to(dev)
-    r = _r(50, 128, dev=dev, seed=4) if res else None
+    x = _r(50, dim, dev=dev, scale=3.0)
+    w, b = (1 + 0.1 * torch.randn(dim)).to(BF).to(dev), (0.1 * torch.randn(dim)).to(BF).to(dev)
+    r = _r(50, dim, dev=dev, seed=4) if res else None
     y = ops.layernorm(x, w, b, 1e-6, residual=r, act=act)
-    ref = F.layer_norm(x.float(), (128,), w.float(), b.float(), 1e-6)
+    ref = F.layer_norm(x.float(), (dim,), w.float(), b.float(), 1e-6)
     if res:
         ref = ref + r.float()
     if act == 3:
         ref = F.silu(ref)
+    if act == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
     assert rel_err(y, ref) < 8e-3
 
 
