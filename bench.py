@@ -180,6 +180,7 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
                        "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}" + ("+sharded-frozen-weights" if a.shard_frozen else ""),
                        "loss": round(float(loss), 6),
+                       "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "token_rows": {"computed": rows_run, "padded_layout": rows_dense,
                                       "note": "padded tail rows (ids == 0) are not computed, like the reference's flash-attn unpadding; results identical"},
                        # executed FLOPs: the per-clip figure scaled by the rows actually run (conservative: the vision tower is not reduced)
