@@ -114,6 +114,12 @@ class VLBLitModule(_Base):
         if getattr(self, "nnmodule", None) is not None:
             return
         cfg = self.config
+        if not cfg.freeze_backbone and not cfg.use_lora:
+            # reference :96-111: everything but the vision tower trains.  The decoder / connector weight gradients
+            # and the 7B-wide optimiser state are not built (BASELINE configs[4]); never fall back silently to a
+            # frozen backbone.
+            raise NotImplementedError("full-parameter fine-tuning (freeze_backbone=False, use_lora=False) is not "
+                                      "implemented: use freeze_backbone=True (configs[1]) or use_lora=True (configs[2-3])")
         g = self.geometry = resolve_geometry(cfg)
         dev = self.device
         torch.cuda.set_device(dev)

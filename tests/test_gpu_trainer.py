@@ -135,3 +135,12 @@ def test_device_prefetcher_hands_over_identical_batches(dev):
                 assert b[k].is_cuda
             assert torch.equal(a[k], b[k].cpu()), k
     assert len(DevicePrefetcher(loader, dev)) == len(loader)
+
+
+def test_full_finetune_config_fails_loudly(dev):
+    """BASELINE configs[4] (freeze_backbone=False, use_lora=False) is not built: it must raise, never train a
+    silently frozen backbone."""
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    m = VLBLitModule(_cfg(freeze_backbone=False, use_lora=False))
+    with pytest.raises(NotImplementedError):
+        m.configure_model()
