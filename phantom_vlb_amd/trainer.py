@@ -99,6 +99,12 @@ class Trainer:
         self.global_step = 0
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        want = devices if isinstance(devices, int) else (len(devices) if isinstance(devices, (list, tuple)) else 1)
+        if want * int(num_nodes or 1) != self.world and self.rank == 0:
+            import warnings
+            warnings.warn(f"trainer.devices={devices} x num_nodes={num_nodes} but this job has WORLD_SIZE={self.world}: "
+                          "one process drives one GPU here - launch with `torchrun --nproc-per-node N train.py ...` "
+                          "to use N GPUs (clip-sharded data parallel over RCCL)")
 
     def _cb(self, hook, *a, **k):
         for c in self.callbacks:
