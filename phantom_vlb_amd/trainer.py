@@ -43,6 +43,8 @@ class TrainableCheckpoint:
         self.best = None
 
     def save(self, module, path, step):
+        if int(os.environ.get("RANK", "0")) != 0:
+            return                      # data parallel: the trainables are replicated, rank 0 writes the one file
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         sd = {n: p.detach().cpu() for n, p in module.trainable_named_parameters()}
         opt = getattr(module, "optimizer", None)
