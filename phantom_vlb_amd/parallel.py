@@ -42,8 +42,8 @@ def init_distributed(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:       # VLB_DIST_BACKEND=gloo lets several ranks rehearse on one GPU
+            backend = os.environ.get("VLB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_device_index())
