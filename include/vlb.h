@@ -62,6 +62,15 @@ int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int l
                   const void* W2, int ldw2, int K2, void* stream);
 
 /* Which kernel vlb_gemm_bf16 picks for a shape: 0 = generic 64x64, 1 = 256x256, 2 = 256x128. */
+/* LoRA backward through dropout in ONE GEMM (peft: dx = dy.W + dropout_mask * (u.A) / (1-p)):
+ *   C[M,N] = A[M,K].W[N,K]^T + keep(m,n)/(1-p) * (A2[M,64].W2[N,64]^T)
+ * keep(m,n) is the counter-based mask of vlb_lora_down / vlb_lora_dx_masked for an [M,N] activation under `seed`
+ * (same bits, so forward and backward agree).  The second pair runs first and the accumulators are masked in
+ * place before the main K loop.  N % 256 == 0, K % 64 == 0, K >= 128, M*N/2 < 2^32; no bias/residual/activation. */
+int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                              const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                              void* stream);
+
 int vlb_gemm_kernel_choice(int M, int N, int K, int K2);
 
 /* out[C,R] = in[R,C]^T (bf16).  Used once per frozen weight to lay down W^T for dgrad. */

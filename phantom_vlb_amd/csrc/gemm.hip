@@ -29,6 +29,9 @@ struct GemmArgs {
   int tile0;                // first parent tile of this launch (the launch covers [tile0, tile0 + grid/split_n))
   int split_n;              // a workgroup computes 1/split_n of a parent tile's columns (tail launches)
   int grid;                 // workgroups of this launch (host side only)
+  // masked second pair (LoRA backward through dropout): C = A.W^T + keep(m,n)/(1-p) * (A2.W2^T), keep from the
+  // counter hash of lora.hip (fast 32-bit path): bits(m, n) = lowbias32((m*(N/2) + n/2) ^ key), 16 bits per column
+  uint32_t drop_thresh, drop_key; float drop_scale;
 };
 
 // blockIdx -> (m0, n0).  XCD-aware: blocks b and b+8 share an XCD, so each XCD gets a contiguous run of the
@@ -517,7 +520,9 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
 // NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
 // of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.  MT = 6: 192-row tiles (wave
 // block 96 rows), picked by the host when they quantise the row count into fewer, fuller waves of tiles.
-template <int NT = 8, int ABL = 0, int MT = 8>
+// MASKED: the second operand pair (one K-tile, K2 = 64) runs FIRST, the accumulators are then multiplied by the
+// dropout keep mask / (1-p) in place, and the main K loop continues on top - dx = dy.W + keep*(u.A)/(1-p) in one GEMM.
+template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
   constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
@@ -546,8 +551,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int r0 = wave * 8 + srow;
   const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
   const int rowA = m0 + r0, rowW = n0 + r0;
-  const int nk1 = p.K / BK;
-  const int nk = nk1 + p.K2 / BK;
+  const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
+  const int nk = p.K / BK + p.K2 / BK;
 
   // LDS-DMA sources = uniform base (SGPR pair, advanced 128 B per K-tile) + a per-instruction 32-bit
   // byte offset held in a VGPR: the loop issues each global_load_lds with no address arithmetic at all.
@@ -564,8 +569,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     curW = reinterpret_cast<const char*>(W_);
   };
   auto select = [&](int kt) {           // call with consecutive kt: positions the bases on K-tile kt
-    if (kt == 0) set_operands(p.A, p.W, p.lda, p.ldw);
-    else if (kt == nk1) set_operands(p.A2, p.W2, p.lda2, p.ldw2);
+    if (kt == 0) { if (MASKED) set_operands(p.A2, p.W2, p.lda2, p.ldw2); else set_operands(p.A, p.W, p.lda, p.ldw); }
+    else if (kt == nk1) { if (MASKED) set_operands(p.A, p.W, p.lda, p.ldw); else set_operands(p.A2, p.W2, p.lda2, p.ldw2); }
     else { curA += ROW_BYTES; curW += ROW_BYTES; }
   };
   auto dma = [&](int buf, int i) {     // instruction i of the selected tile (0..A_LD-1: A, then W)
@@ -672,6 +677,41 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   };
   using T_ = std::true_type; using F_ = std::false_type;
   int kt = 0;
+  if constexpr (MASKED) {
+    // K-tile 0 = the LoRA pair u.A (host guarantees K2 == 64 and nk >= 3); then keep/(1-p) on the accumulators
+    tile(0, T_{}, T_{});
+    kt = 1;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; j += 4)
+        asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1]), "+a"(acc[i][j + 2]), "+a"(acc[i][j + 3]));
+    const int frm = lane & 15, fqm = lane >> 4;
+    const uint32_t halfN = (uint32_t)(p.N >> 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const uint32_t rb = (uint32_t)(m0 + wm * TM + i * 16 + frm) * halfN;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint32_t pair0 = (uint32_t)(n0 + wn * TN + j * 16 + fqm * 4) >> 1;
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint32_t h = (rb + pair0 + q) ^ p.drop_key;
+          h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;      // lowbias32
+          v[2 * q] = (h & 0xffffu) >= p.drop_thresh ? v[2 * q] * p.drop_scale : 0.f;
+          v[2 * q + 1] = (h >> 16) >= p.drop_thresh ? v[2 * q + 1] * p.drop_scale : 0.f;
+        }
+        acc[i][j] = v;
+        // straight back into its AGPR tuple, one tile at a time: keeps the VGPR live set (fragments of the next
+        // K-tile are already in flight) small and the allocator from parking accumulators in VGPRs
+        asm volatile("" : "+a"(acc[i][j]));
+        W4_FENCE();
+      }
+    }
+    asm volatile("s_nop 7" ::: "memory");          // VALU writes of the accumulators settle before the next MFMA reads them
+  }
   for (; kt + 2 < nk; ++kt) tile(kt, T_{}, T_{});
   if (kt + 1 < nk) { tile(kt, T_{}, F_{}); ++kt; }
   tile(kt, F_{}, F_{});
@@ -733,12 +773,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   }
 }
 
-template <int NT, int ABL, int MT = 8>
+template <int NT, int ABL, int MT = 8, bool MASKED = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -746,7 +786,7 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -893,7 +933,7 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   a.bias = (const bf16*)bias; a.residual = (const bf16*)residual;
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
-  a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
+  a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
@@ -952,6 +992,62 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
+}
+
+namespace {
+inline uint32_t lowbias32_h(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+}  // namespace
+
+extern "C" int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                         const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                                         void* stream) {
+  VLB_REQUIRE(A && W && C && A2 && W2, "gemm_masked_pair: null operand");
+  VLB_REQUIRE(M > 0 && N % 256 == 0 && K >= 128 && K % 64 == 0, "gemm_masked_pair: needs N %% 256 == 0, K %% 64 == 0, K >= 128 (N=%d K=%d)", N, K);
+  VLB_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && lda >= K && ldw >= K && lda2 >= 64 && ldw2 >= 64 &&
+                  ldc % 4 == 0 && ldc >= N, "gemm_masked_pair: bad leading dimensions");
+  VLB_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2) % 16) == 0 && ((uintptr_t)C % 8) == 0,
+              "gemm_masked_pair: operands must be 16-byte aligned");
+  VLB_REQUIRE(drop_p > 0.f && drop_p < 1.f, "gemm_masked_pair: drop_p must be in (0,1) - use vlb_gemm_bf16 when p == 0");
+  VLB_REQUIRE((int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) && (int64_t)M * lda2 < (1ll << 31) &&
+                  (int64_t)N * ldw2 < (1ll << 31) && (int64_t)M * (N >> 1) < (1ll << 32),
+              "gemm_masked_pair: operand too large for 32-bit offsets / the 32-bit dropout counter");
+  GemmArgs a;
+  a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = (bf16*)C;
+  a.A2 = (const bf16*)A2; a.W2 = (const bf16*)W2;
+  a.bias = nullptr; a.residual = nullptr;
+  a.M = M; a.N = N; a.K = K; a.K2 = 64;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0; a.lda2 = lda2; a.ldw2 = ldw2;
+  a.act = VLB_ACT_NONE; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
+  uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
+  a.drop_thresh = t > 65535u ? 65535u : t;
+  a.drop_key = lowbias32_h(seed);
+  a.drop_scale = 1.f / (1.f - drop_p);
+  hipStream_t s = as_stream(stream);
+  // same wave-quantisation choice as vlb_gemm_bf16 (256- or 192-row tiles, re-cut partial wave)
+  const int cus = 256, tn = N / 256;
+  auto waves = [&](int t_, bool& split) {
+    const int full = t_ / cus, r = t_ % cus;
+    split = g_tail_split && t_ > cus && r != 0 && r <= cus * 5 / 8;
+    return (double)full + (r == 0 ? 0.0 : (split ? 0.62 : 1.0));
+  };
+  bool s256, s192;
+  const int tm256 = (M + 255) / 256, tm192 = (M + 191) / 192;
+  const int t256 = tm256 * tn, t192 = tm192 * tn;
+  const double c256 = waves(t256, s256) * 256.0, c192 = waves(t192, s192) * 192.0 * 1.02;
+  const bool use192 = t256 > cus && c192 < 0.97 * c256;
+  const int tiles = use192 ? t192 : t256, rem = tiles % cus;
+  const bool split = use192 ? s192 : s256;
+  GemmArgs hi = a;
+  hi.tiles_m = use192 ? tm192 : tm256; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
+  hi.grid = split ? tiles - rem : tiles;
+  int rc = use192 ? launch_w4<8, 0, 6, true>(hi, s) : launch_w4<8, 0, 8, true>(hi, s);
+  if (rc != VLB_OK || !split) return rc;
+  GemmArgs lo = hi;
+  lo.tile0 = tiles - rem; lo.split_n = 2; lo.grid = 2 * rem;
+  return use192 ? launch_w4<4, 0, 6, true>(lo, s) : launch_w4<4, 0, 8, true>(lo, s);
 }
 
 // tuning hooks (not part of the stable ABI): kernel variant / forced tile

@@ -266,6 +266,10 @@ class LoraState:
             return None
         if self.p == 0.0:
             return ops.gemm(dy, W_t, a2=u, w2=lay["At"])
+        if lay["R"] == 16 and ops.gemm_masked_pair_ok(dy.shape[0], W_t.shape[0], dy.shape[1]):
+            # single-projection groups (o, down): the dropout mask is applied to the u.A accumulators inside the
+            # dgrad GEMM - no read-modify-write pass over dx
+            return ops.gemm_masked_pair(dy, W_t, u, lay["At"], self.p, seeds[0])
         dx = ops.gemm(dy, W_t)
         lora_dx_masked(u, lay["At"], dx, lay["R"], self.p, seeds)
         return dx

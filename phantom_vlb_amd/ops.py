@@ -83,6 +83,25 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     return out
 
 
+def gemm_masked_pair_ok(M, N, K):
+    """Shapes vlb_gemm_bf16_masked_pair accepts (the fused LoRA dx path); callers fall back to gemm + lora_dx_masked."""
+    return N % 256 == 0 and K % 64 == 0 and K >= 128 and M * (N // 2) < 2 ** 32
+
+
+def gemm_masked_pair(a, w, a2, w2, p, seed, out=None):
+    """out[M,N] = a @ w^T + keep(m,n)/(1-p) * (a2[:, :64] @ w2[:, :64]^T): LoRA backward through dropout in one GEMM."""
+    _dev(a)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a2.shape[0] == M and w2.shape[0] == N and a2.shape[1] >= 64 and w2.shape[1] >= 64
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    check(lib.vlb_gemm_bf16_masked_pair(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                        M, N, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), float(p),
+                                        int(seed) & 0xFFFFFFFF, _stream()), "vlb_gemm_bf16_masked_pair")
+    return out
+
+
 def interleave_gate_up(w_gate, w_up):
     """[gate; up] -> 16-row blocks [gate_0 | up_0 | gate_1 | up_1 | ...] for ACT_SWIGLU_PAIR."""
     ff, k = w_gate.shape

@@ -267,3 +267,33 @@ def test_mini_lora_dropout_matches_oracle(dev):
               "model.layers.0.mlp.up_proj.lora_B.weight", "model.layers.1.self_attn.v_proj.lora_B.weight"):
         got = m.lora.grads[n].t() if "lora_B" in n else m.lora.grads[n]
         assert rel_err(got, pr[n].grad) < 6e-2, n
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (5861, 4096, 4096), (3000, 1024, 4096)])
+def test_gemm_masked_pair_equals_gemm_plus_lora_dx(dev, M, N, K):
+    """dx = dy.W + keep*(u.A)/(1-p) in one GEMM (mask applied to the LoRA accumulators in place) against the
+    two-kernel path; the mask bits must be the very same (forward used them), the values agree to bf16 rounding."""
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd.lora import PAD, lora_dx_masked
+    g = torch.Generator().manual_seed(M + N)
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(dev)
+    u = torch.zeros(M, PAD, dtype=BF)
+    u[:, :16] = (torch.randn(M, 16, generator=g) * 0.5).to(BF)
+    At = torch.zeros(N, PAD, dtype=BF)
+    At[:, :16] = (torch.randn(N, 16, generator=g) * 0.2).to(BF)
+    u, At = u.to(dev), At.to(dev)
+    seed, p = 0x1234ABCD, 0.1
+    assert ops.gemm_masked_pair_ok(M, N, K)
+    fused = ops.gemm_masked_pair(dy, W, u, At, p, seed)
+    base = ops.gemm(dy, W)
+    two = base.clone()
+    lora_dx_masked(u, At, two, 16, p, [seed])
+    # reference in fp32 with the mask recovered from the two-kernel path: delta != 0 <=> kept (u.A is dense)
+    lora = (u[:, :16].float() @ At[:, :16].float().t()) / (1 - p)
+    keep = keep_mask(seed, M, N, p).to(dev)
+    ref = dy.float() @ W.float().t() + lora * keep
+    assert rel_err(fused, ref) < 6e-3
+    assert rel_err(two, ref) < 1.2e-2            # the two-kernel path rounds to bf16 twice
+    kept_frac = float(keep.float().mean())
+    assert abs(kept_frac - 0.9) < 0.01
