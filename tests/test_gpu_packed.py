@@ -179,3 +179,31 @@ def test_training_step_packed_equals_dense(dev, lora):
         else:
             denom = gd.abs().max().clamp_min(1e-12)
             assert (gp - gd).abs().max() / denom < 5e-3, n
+
+
+def test_packed_step_edge_batches(dev):
+    """Edge batches: a single clip, a clip without any padding (len == max_len), and one with the largest padding
+    the generator produces - packed == dense for loss and head gradients in every case."""
+    from oracle import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    g = O.geometry_mini()
+    S = g.max_len
+    for B, seed in ((1, 3), (2, 4), (4, 5)):
+        batch = O.synthetic_batch(g, B, seed=seed)
+        # force clip 0 to carry no padding at all: fill its padded tail with ordinary token ids
+        ids = batch["language"].clone()
+        pad0 = int(batch["padvals"][0, 0])
+        if pad0:
+            ids[0, ids.shape[1] - pad0:] = 7.0
+        batch = dict(batch, language=ids)
+        res = {}
+        for pack in (False, True):
+            m = VLBLitModule(_cfg(pack_tokens=pack))
+            m.configure_model()
+            m.configure_optimizers()
+            if pack:
+                lay = m.backbone.row_layout(batch["language"], batch["padvals"])
+                assert lay.lens[0] == S                     # nothing to drop for clip 0
+            res[pack] = (float(m.training_step(batch)), m.flat.grad.clone())
+        assert res[True][0] == res[False][0]
+        assert torch.equal(res[True][1], res[False][1])
