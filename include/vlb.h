@@ -92,11 +92,13 @@ int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk, const void
                       float* lse, const uint8_t* key_mask, int B, int S, int Hq, int Hkv, int D, int causal,
                       float scale, const int* cu_rows, void* stream);
 
-/* Backward of the above. dq/dk/dv have the layout/strides of q/k/v.  delta: [B,Hq,S] fp32 workspace.
- * Three launches: delta = rowsum(dout*out); dK/dV (key-block outer loop); dQ (query-block outer loop,
- * accumulated in registers: no atomics, reproducible).  dq_acc: unused by the default path, may be NULL
- * (fp32 [rows,Hq,D] scratch of the selectable atomic-dQ variant).  total_rows = cu_rows[B] (host copy;
- * ignored when cu_rows == NULL, where rows = B*S). */
+/* Backward of the above. dq/dk/dv have the layout/strides of q/k/v (dk/dv rows 16-byte aligned).
+ * delta: [B,Hq,S] fp32 workspace.  dq_acc: workspace of rows*Hq*D fp32 elements (rows = total_rows or B*S); with
+ * grouped-query heads it holds the per-q-head bf16 partials of dK/dV (may be NULL when Hq == Hkv).
+ * Launches: delta = rowsum(dout*out); dK/dV with one workgroup per (128 keys, q-head) - the causal triangle is
+ * spread over Hq/Hkv times more workgroups than a per-kv-head sweep; a fixed-order sum of each GQA group's partials
+ * (bf16 partials, as autograd's repeat_kv backward produces); dQ (query-block outer loop, accumulated in registers).
+ * No atomics: results are reproducible.  total_rows = cu_rows[B] (host copy; ignored when cu_rows == NULL). */
 int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
                       int ldo, const void* dout, int lddo, const float* lse, const uint8_t* key_mask, void* dq,
                       int lddq, void* dk, int lddk, void* dv, int lddv, float* delta, float* dq_acc, int B, int S,

@@ -310,7 +310,8 @@ constexpr int BK_KEYS = 128;   // keys per workgroup
 constexpr int BQ = 32;         // queries per inner block
 
 int g_attn_ablate = 0;
-int g_attn_split_dq = 1;      // 1: dQ in its own register-accumulating pass (default), 0: fp32 atomics from the dK/dV kernel
+int g_attn_split_dq = 1;      // 1 (default): per-q-head dK/dV workgroups + dQ pass; 2: the 8-wave per-kv-head dK/dV kernel + dQ pass;
+                              // 0: 8-wave kernel with fp32 dQ atomics (A/B only)
 struct AttnBwdArgs {
   const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
   const float* lse; const float* delta; const uint8_t* mask; const int* cu;
@@ -618,6 +619,208 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// dK / dV pass, one workgroup per (128 keys, q-head).  The causal triangle gives the first key block 16x the work
+// of the last; sweeping all q-heads of a GQA group inside one workgroup (the 8-wave kernel above) makes that
+// workgroup the critical path.  Here every q-head is its own workgroup (4x more, 4x shorter, heaviest first), the
+// per-head partials are written as bf16 - which is also what autograd does for the reference's repeat_kv, whose
+// backward sums the expanded heads in bf16 - and attn_dkdv_reduce_kernel adds them in a fixed order.
+// 4 waves x 32 keys, K fragments in REGISTERS for the whole kernel, V tile in LDS once, 32-row Q/dO tiles through a
+// double-buffered LDS-DMA ring; 65 KB of LDS: two workgroups per CU; one barrier per 32 queries.
+// -------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p, bf16* __restrict__ part) {
+  constexpr int D = 128, ROWB = 256;
+  constexpr int V_OFF = 0;                                          // V tile: 128 keys x 256 B = 32 KB
+  constexpr int QT_BYTES = BQ * ROWB;                               // 8 KB
+  constexpr int Q_OFF = BK_KEYS * ROWB;                             // [2][Q tile | dO tile] = 32 KB
+  constexpr int L_OFF = Q_OFF + 4 * QT_BYTES;                       // [2][lse 32 | delta 32] f32 = 512 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+  const int gsz = p.Hq / p.Hkv;
+  const int hkv = hq / gsz;
+  const int k0 = kb * BK_KEYS;
+  const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
+  const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
+  if (k0 >= Sb) return;
+  const int ql = lane & 31, h = lane >> 5;
+  const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int sr = lane >> 4, sp = lane & 15;
+
+  const int krow = w4 * 32 + ql;
+  const int key = k0 + krow;
+  // K fragments (B operand of S = Q.K^T): lane holds K[key][16ks + 8h + j]
+  bf16x8 kf[8];
+  {
+    const bf16* kp = p.k + (row0 + min(key, Sb - 1)) * p.ldk + hkv * D + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+  }
+  const bf16* vbase = p.v + row0 * p.ldv + hkv * D;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int piece = 4 * i + w4, r = piece * 4 + sr;
+    glds16(vbase + (int64_t)min(k0 + r, Sb - 1) * p.ldv + (sp ^ sw2(r)) * 8, smem + V_OFF + piece * 1024);
+  }
+  const int nqb = (Sb + BQ - 1) / BQ;
+  const int qb0 = CAUSAL ? (k0 / BQ) : 0;
+  const int total = nqb - qb0;
+  const bf16* qbase = p.q + row0 * p.ldq + hq * D;
+  const bf16* dobase = p.dout + row0 * p.lddo + hq * D;
+  const float* lsebase = p.lse + ((int64_t)b * p.Hq + hq) * p.S;
+  const float* delbase = p.delta + ((int64_t)b * p.Hq + hq) * p.S;
+
+  auto stage_q = [&](int buf, int item) {
+    const int qb = qb0 + item;
+    char* qt = smem + Q_OFF + buf * 2 * QT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 4 * i + w4, r = piece * 4 + sr;
+      const int qr = min(qb * BQ + r, Sb - 1);
+      glds16(qbase + (int64_t)qr * p.ldq + (sp ^ sw2(r)) * 8, qt + piece * 1024);
+      glds16(dobase + (int64_t)qr * p.lddo + (sp ^ sw2(r)) * 8, qt + QT_BYTES + piece * 1024);
+    }
+    if (w4 == 0) {
+      const int qr = min(qb * BQ + (lane & 31), Sb - 1);
+      const float* src = (lane < 32 ? lsebase : delbase) + qr;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(smem + L_OFF + buf * 256), 4, 0, 0);
+    }
+  };
+
+  f32x16 dkt[4], dvt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
+
+  if (total > 0) stage_q(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // row-read offsets are formed at the use site: chunk (2ks + h) ^ sw2(row) = (2ks) ^ (h ^ sw2(row)), 2ks even
+  const int v_base = krow * ROWB, v_x = h ^ sw2(krow);
+  const int q_base = ql * ROWB, q_x = h ^ sw2(ql);
+  int qt_rd[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 8 * e + 4 * h + tq;
+      qt_rd[dt][e] = r * ROWB + (((4 * dt + 2 * g1 + (tp >> 1)) ^ sw2(r)) << 4) + (tp & 1) * 8;
+    }
+
+  const float c2 = p.scale * 1.44269504088896341f;
+  bool key_ok = key < Sb;
+  if (key_ok && p.mask) key_ok = p.mask[row0 + key] != 0;
+
+  for (int item = 0; item < total; ++item) {
+    const int cur = item & 1;
+    if (item + 1 < total) stage_q(cur ^ 1, item + 1);
+    const char* qt = smem + Q_OFF + cur * 2 * QT_BYTES;
+    const char* dot = qt + QT_BYTES;
+    const float* ls = reinterpret_cast<const float*>(smem + L_OFF) + cur * 64;
+    const int q0 = (qb0 + item) * BQ;
+    const bool active = !CAUSAL || (k0 + w4 * 32 <= q0 + BQ - 1);     // else: this wave's keys all follow the block
+    if (active) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + q_base + (((2 * ks) ^ q_x) << 4));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
+        const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_base + (((2 * ks) ^ q_x) << 4));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + v_base + (((2 * ks) ^ v_x) << 4));
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
+      }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int qrow = q0 + 8 * g + 4 * h + e;
+          bool ok = key_ok && qrow < Sb;
+          if (CAUSAL) ok = ok && (key <= qrow);
+          const float pv = ok ? __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[e] * 1.44269504088896341f) : 0.f;
+          const float ds = pv * (pacc[r] - d4[e]) * p.scale;
+          pb[r >> 3][r & 7] = (bf16)pv;
+          dsb[r >> 3][r & 7] = (bf16)ds;
+        }
+      }
+      // dV^T += dO^T.P ; dK^T += Q^T.dS: the transposed fragments of one operand at a time (live set < 256 registers)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s16x4 ra[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) ra[dt][e] = tr_read_asm(dot + qt_rd[dt][e] + 16 * s * ROWB);
+        lds_wait_all();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ra[dt][0], ra[dt][1]), pb[s], dvt[dt], 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) ra[dt][e] = tr_read_asm(qt + qt_rd[dt][e] + 16 * s * ROWB);
+        lds_wait_all();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(ra[dt][0], ra[dt][1]), dsb[s], dkt[dt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next Q/dO tile landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // ... for every wave, and the current tile is free again
+  }
+
+  if (key < Sb) {
+    // a lone head per kv-head (no GQA) writes dK / dV directly, otherwise its bf16 partial [row][Hq][dK 128 | dV 128]
+    bf16* dkp = gsz == 1 ? p.dk + (row0 + key) * p.lddk + hkv * D : part + ((row0 + key) * p.Hq + hq) * (2 * D);
+    bf16* dvp = gsz == 1 ? p.dv + (row0 + key) * p.lddv + hkv * D : dkp + D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (bf16)dkt[dt][4 * g + e]; c[e] = (bf16)dvt[dt][4 * g + e]; }
+        *reinterpret_cast<bf16x4*>(dkp + 32 * dt + 8 * g + 4 * h) = a;
+        *reinterpret_cast<bf16x4*>(dvp + 32 * dt + 8 * g + 4 * h) = c;
+      }
+  }
+}
+
+// dk / dv [row][hkv*128 + d] = sum over the GQA group's q-heads of their bf16 partials (fp32 sum, fixed order)
+__global__ __launch_bounds__(256) void attn_dkdv_reduce_kernel(const bf16* __restrict__ part, bf16* __restrict__ dk, int lddk,
+                                                               bf16* __restrict__ dv, int lddv, int Hq, int Hkv, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;          // (row, hkv, which, 16-byte chunk of 128 d)
+  if (i >= total) return;
+  const int c = i & 15, which = (i >> 4) & 1;
+  const int hkv = (int)((i >> 5) % Hkv);
+  const int64_t row = (i >> 5) / Hkv;
+  const int gsz = Hq / Hkv;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16* src = part + (row * Hq + (int64_t)hkv * gsz) * 256 + which * 128 + c * 8;
+  for (int j = 0; j < gsz; ++j) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)j * 256);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+  bf16* dst = which ? dv + row * lddv : dk + row * lddk;
+  *reinterpret_cast<bf16x8*>(dst + hkv * 128 + c * 8) = o;
+}
+
+// -------------------------------------------------------------------------------------------------
 // dQ in its own pass, shaped like the forward kernel: a workgroup owns 128 query rows of one q-head and
 // sweeps the key tiles, so dQ accumulates in registers - no fp32 atomics, no scratch buffer, and a fixed
 // summation order (bit-reproducible).  Per 64-key tile a wave recomputes S^T = K.Q^T and dP^T = V.dO^T
@@ -821,7 +1024,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
                                  int S, int Hq, int Hkv, int D, int causal, float scale, const int* cu_rows, int total_rows,
                                  void* stream) {
   VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "attention_bwd: null operand");
-  VLB_REQUIRE(g_attn_split_dq || dq_acc, "attention_bwd: the atomic dQ variant needs the dq_acc workspace");
+  VLB_REQUIRE(dq_acc || g_attn_split_dq == 2 || (g_attn_split_dq == 1 && Hq == Hkv), "attention_bwd: the fp32 [rows, Hq, D] workspace is required");
   VLB_REQUIRE(D == 128, "attention_bwd: head dim %d unsupported (only 128: the decoder)", D);
   VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
   VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&
@@ -849,8 +1052,32 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
     configured = true;
   }
   dim3 grid((S + BK_KEYS - 1) / BK_KEYS, Hkv, B);
-  if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
-  else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
+  if (split == 1) {
+    const int gsz = Hq / Hkv;
+    VLB_REQUIRE(gsz == 1 || dq_acc, "attention_bwd: the workspace (fp32 [rows, Hq, D]) is required for grouped-query heads");
+    VLB_REQUIRE(lddk % 8 == 0 && lddv % 8 == 0 && (((uintptr_t)dk | (uintptr_t)dv) % 16) == 0, "attention_bwd: dk/dv rows must be 16-byte aligned");
+    constexpr int LDS_KV = BK_KEYS * 256 + 4 * BQ * 256 + 512;        // 65 KB: two workgroups per CU
+    static bool configured_kv = false;
+    if (!configured_kv) {
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+      if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dk/dv)"); return VLB_ERR_LAUNCH; }
+      configured_kv = true;
+    }
+    bf16* part = reinterpret_cast<bf16*>(dq_acc);        // rows*Hq*256 bf16 = the same bytes as fp32 [rows, Hq, 128]
+    dim3 gridh(grid.x, Hq, B);                           // heaviest key blocks are dispatched first
+    if (causal) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gridh, dim3(256), LDS_KV, st, a, part);
+    else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gridh, dim3(256), LDS_KV, st, a, part);
+    VLB_LAUNCH_CHECK();
+    if (gsz > 1) {
+      const int64_t tot = rows * Hkv * 32;
+      hipLaunchKernelGGL(attn_dkdv_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part, (bf16*)dk, lddk,
+                         (bf16*)dv, lddv, Hq, Hkv, tot);
+    }
+  } else {
+    if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
+  }
   VLB_LAUNCH_CHECK();
   if (split) {
     AttnDqArgs d{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
@@ -877,4 +1104,4 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
 }
 
 // tuning hook (not part of the stable ABI): timing-only ablations of the attention backward kernel
-extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits & 3; g_attn_split_dq = (bits & 4) ? 0 : 1; }   // bit2: legacy atomic dQ
+extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits & 3; g_attn_split_dq = (bits & 4) ? 0 : ((bits & 8) ? 2 : 1); }   // bit2: atomic dQ; bit3: 8-wave dK/dV + dQ pass

@@ -171,6 +171,17 @@ def attention_fwd(q, k, v, B, S, Hq, Hkv, D, causal, scale, key_mask=None, need_
     return (out, lse) if need_lse else out
 
 
+_ATTN_WS = [None]
+
+
+def _attn_workspace(n_floats, device):
+    """Grow-only fp32 scratch for vlb_attention_bwd (per-q-head dK/dV partials), shared by all layers."""
+    ws = _ATTN_WS[0]
+    if ws is None or ws.numel() < n_floats or ws.device != device:
+        ws = _ATTN_WS[0] = torch.empty(n_floats, dtype=torch.float32, device=device)
+    return ws
+
+
 def attention_bwd(qkv, qd, kd, out, dout, lse, key_mask, B, S, Hq, Hkv, D, causal, scale, layout=None, delta=None,
                   dq_acc=None):
     """Backward through attention_fwd on a fused [rows, qd+2*kd] qkv buffer -> dqkv of the same shape."""
@@ -180,6 +191,8 @@ def attention_bwd(qkv, qd, kd, out, dout, lse, key_mask, B, S, Hq, Hkv, D, causa
     assert qkv.shape[0] == rows and dout.shape[0] == rows
     if delta is None:
         delta = torch.empty(B, Hq, S, dtype=torch.float32, device=qkv.device)
+    if dq_acc is None and Hq != Hkv:
+        dq_acc = _attn_workspace(rows * qd, qkv.device)
     assert delta.numel() >= B * Hq * S and (dq_acc is None or dq_acc.numel() >= rows * qd)
     dqkv = torch.empty_like(qkv)
     check(lib.vlb_attention_bwd(qkv.data_ptr(), qkv.stride(0), qkv[:, qd:].data_ptr(), qkv.stride(0),

@@ -169,7 +169,7 @@ def test_attention_bwd(dev, B, S, Hq, Hkv, causal, masked):
             legacy = ops.attention_bwd(dq_, qd, kd, out, dout_d, lse, dmask, B, S, Hq, Hkv, D, causal, D ** -0.5, dq_acc=acc)
         finally:
             lib.vlb_attn_set_ablation(0)
-        assert torch.equal(legacy[:, qd:], dqkv[:, qd:])                    # dK / dV: same kernel, same order
+        assert rel_err(legacy[:, qd:], dqkv[:, qd:].float()) < 1e-2         # dK / dV: per-kv-head fp32 sums vs per-q-head bf16 partials
         assert rel_err(legacy[:, :qd], dqkv[:, :qd].float()) < 1e-2         # dQ: atomics vs register accumulation
     got = dqkv.float().cpu()
     assert rel_err(got[:, :qd].view(B, S, Hq, D), dq_ref) < 2e-2

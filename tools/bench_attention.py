@@ -33,7 +33,7 @@ print(f"fwd  {t*1e6:8.1f} us  {fwd_flops/t/1e12:6.1f} TF/s")
 modes = [0]
 if hasattr(lib, "vlb_attn_set_ablation"):
     lib.vlb_attn_set_ablation.argtypes = [ctypes.c_int]; lib.vlb_attn_set_ablation.restype = None
-    modes = [0, 4, 5, 6]        # 0: split dQ pass (default); 4: legacy atomic dQ; 5/6: its timing-only ablations
+    modes = [0, 8, 4]           # 0: per-q-head dK/dV + dQ pass (default); 8: 8-wave per-kv-head dK/dV + dQ pass; 4: atomic dQ
 for m in modes:
     lib.vlb_attn_set_ablation(m) if len(modes) > 1 else None
     acc = torch.empty(B * S, qd, dtype=torch.float32, device=dev) if m & 4 else None
