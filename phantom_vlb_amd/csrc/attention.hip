@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.S + QB - 1) / QB;
-  const int qb = CAUSAL ? (nqb - 1 - blockIdx.x) : blockIdx.x;   // heavy (late) causal blocks first
-  const int hq = blockIdx.y, b = blockIdx.z;
+  // 1-D grid ordered by weight over the whole launch: with a causal mask every workgroup of the last query block
+  // (the most key tiles) is dispatched before any of the previous one, for all heads and clips
+  const int per_qb = p.Hq * p.B, slot = blockIdx.x / per_qb;
+  const int qb = CAUSAL ? (nqb - 1 - slot) : slot;
+  const int hq = (blockIdx.x % per_qb) % p.Hq, b = (blockIdx.x % per_qb) / p.Hq;
   const int hkv = hq / (p.Hq / p.Hkv);
   const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;                 // tokens of this clip
   const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;            // its first row
@@ -272,7 +275,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) { vlb_set_error("attention: LDS reservation failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
     configured = true;
   }
-  dim3 grid((a.S + QB - 1) / QB, a.Hq, a.B);
+  dim3 grid(((a.S + QB - 1) / QB) * a.Hq * a.B);
   hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), grid, dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
@@ -638,7 +641,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p, bf
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kb = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+  // 1-D grid ordered by weight: every workgroup of key block 0 (the most query blocks under the causal mask) is
+  // dispatched before any of key block 1, and so on - longest jobs first over the whole launch
+  const int per_kb = p.Hq * p.B;
+  const int kb = blockIdx.x / per_kb, hq = (blockIdx.x % per_kb) % p.Hq, b = (blockIdx.x % per_kb) / p.Hq;
   const int gsz = p.Hq / p.Hkv;
   const int hkv = hq / gsz;
   const int k0 = kb * BK_KEYS;
@@ -845,8 +851,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnDqArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.S + QB - 1) / QB;
-  const int qb = CAUSAL ? (nqb - 1 - blockIdx.x) : blockIdx.x;   // heavy (late) causal blocks first
-  const int hq = blockIdx.y, b = blockIdx.z;
+  // 1-D grid ordered by weight over the whole launch: with a causal mask every workgroup of the last query block
+  // (the most key tiles) is dispatched before any of the previous one, for all heads and clips
+  const int per_qb = p.Hq * p.B, slot = blockIdx.x / per_qb;
+  const int qb = CAUSAL ? (nqb - 1 - slot) : slot;
+  const int hq = (blockIdx.x % per_qb) % p.Hq, b = (blockIdx.x % per_qb) / p.Hq;
   const int hkv = hq / (p.Hq / p.Hkv);
   const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
   const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
@@ -1065,7 +1074,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
       configured_kv = true;
     }
     bf16* part = reinterpret_cast<bf16*>(dq_acc);        // rows*Hq*256 bf16 = the same bytes as fp32 [rows, Hq, 128]
-    dim3 gridh(grid.x, Hq, B);                           // heaviest key blocks are dispatched first
+    dim3 gridh(grid.x * Hq * B);                         // 1-D, heaviest key blocks first (see the kernel)
     if (causal) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gridh, dim3(256), LDS_KV, st, a, part);
     else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, gridh, dim3(256), LDS_KV, st, a, part);
     VLB_LAUNCH_CHECK();
@@ -1090,7 +1099,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
       if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dq)"); return VLB_ERR_LAUNCH; }
       configured_dq = true;
     }
-    dim3 gq((S + QB - 1) / QB, Hq, B);
+    dim3 gq(((S + QB - 1) / QB) * Hq * B);
     if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), LDS_DQ, st, d);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), LDS_DQ, st, d);
     VLB_LAUNCH_CHECK();
