@@ -214,13 +214,18 @@ class LoraState:
     def forward(self, backbone, vision_f32, ids, layout=None):
         """Training forward of the whole backbone; decoder activations are kept for backward.
         ``layout``: packed RowLayout (rows without the clips' padded tails) or None for dense [B,S]."""
-        g, w = self.g, self.w
+        g = self.g
         B = vision_f32.shape[0]
-        S = g.max_len
-        pos = None if layout is None else layout.pos
         pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
         vid = backbone.connector(backbone.vision_tower(pix), B)          # frozen: no activations kept
         x, key_mask = backbone.splice(ids, vid, layout)
+        return self.decoder_forward(backbone, x, key_mask, B, layout)
+
+    def decoder_forward(self, backbone, x, key_mask, B, layout=None):
+        """The adapted decoder on spliced embeddings x [rows, dim] (the part of forward() that keeps activations)."""
+        g, w = self.g, self.w
+        S = g.max_len
+        pos = None if layout is None else layout.pos
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         self.saved = []
         self.step += 1

@@ -227,3 +227,70 @@ def test_7b_step_packed_equals_dense(dev):
     assert torch.equal(res[True][1], res[False][1])
     del m
     torch.cuda.empty_cache()
+
+
+def test_lora_decoder_layer_full_size_fwd_bwd_vs_oracle(dev):
+    """One Mistral-7B-sized decoder layer with LoRA r=16 (dropout 0.1) on one 2048-token clip, 150 padded positions:
+    forward output and the gradients of all 14 adapter matrices against the oracle's autograd, the oracle being fed
+    the very masks the kernels used.  Exercises at BASELINE sizes: fused LoRA GEMMs (second operand pair), the
+    four-wave GEMM with 192/256-row tiles and re-cut tails, attention forward, dK/dV + GQA reduce + dQ, the fused
+    dB/u skinny wgrad, the masked-pair dgrad GEMM and lora_dx."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd.backbone import Backbone, Weights
+    from phantom_vlb_amd.geometry import geometry_7b
+    from phantom_vlb_amd.lora import GROUPS, LoraState
+    from test_gpu_lora import keep_mask
+    go = dataclasses.replace(O.geometry_7b(lora_r=16, lora_alpha=32), layers=1, vit_layers=2, proj_depth=1)
+    full = O.init_params(go, seed=11, lora=True, lora_b_std=0.02)
+    p = O.round_bf16({k: v for k, v in full.items() if k.startswith(("model.layers.0.", "model.norm"))})
+    S = 2048
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.randn(1, S, go.dim, generator=gen) * 0.5).to(BF)
+    gout = (torch.randn(1, S, go.dim, generator=gen) * 0.1).to(BF)
+    mask = torch.ones(1, S, dtype=torch.bool)
+    mask[0, S - 150:] = False
+    gout[0, S - 150:] = 0                                  # the head never weights padded rows
+    # ---- device: one-layer weights (with the transposed copies LoRA's dgrad needs) + adapters from the same dict
+    g = dataclasses.replace(geometry_7b(lora_r=16, lora_alpha=32), layers=1)
+    w = Weights.__new__(Weights)
+    w.g, w.dev = g, dev
+    lw = {"in_norm": p["model.layers.0.input_layernorm.weight"], "post_norm": p["model.layers.0.post_attention_layernorm.weight"],
+          "wqkv": torch.cat([p[f"model.layers.0.self_attn.{n}_proj.weight"] for n in "qkv"], 0),
+          "wo": p["model.layers.0.self_attn.o_proj.weight"], "wdown": p["model.layers.0.mlp.down_proj.weight"],
+          "wgu": torch.cat([p["model.layers.0.mlp.gate_proj.weight"], p["model.layers.0.mlp.up_proj.weight"]], 0)}
+    lw = {k: v.to(dev, BF).contiguous() for k, v in lw.items()}
+    for k in ("wqkv", "wo", "wgu", "wdown"):
+        lw[k + "_t"] = ops.transpose(lw[k])
+    w.layers = [lw]
+    w.final_norm = p["model.norm.weight"].to(dev, BF)
+    inv = 1.0 / (g.rope_theta ** (torch.arange(0, g.head_dim, 2, dtype=torch.float32) / g.head_dim))
+    fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
+    w.rope_cos, w.rope_sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+    bb = Backbone(g, w)
+    lora = LoraState(g, w, 16, 32, 0.1, dev, sd=p)
+    hidden, _ = lora.decoder_forward(bb, x.to(dev).view(S, g.dim).clone(), mask.to(torch.uint8).to(dev), 1)
+    lora.backward(bb, gout.to(dev).view(S, g.dim).contiguous())
+    torch.cuda.synchronize()
+    # ---- oracle with the same dropout masks (step counter is 1 after the first forward)
+    drop, idx = {}, 0
+    for gname, targets in GROUPS:
+        for t in targets:
+            K = lora.in_dims[t]
+            drop[f"model.layers.0.{t}"] = (keep_mask(lora._seed(0, idx), S, K, 0.1).float() / 0.9).view(1, S, K)
+            idx += 1
+    names = [k for k in p if ".lora_" in k]
+    pr = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in p.items()}
+    ref = O.mistral_decoder(pr, x.float(), mask, go, lora_drop=drop)
+    (ref * gout.float()).sum().backward()
+    got = hidden.view(1, S, g.dim).float().cpu()
+    err = ((got - ref.detach()).abs() * mask[..., None]).max() / ref.detach().abs().max()
+    assert err < 2e-2, err
+    worst = 0.0
+    for n in names:
+        gpu = lora.grads[n].t() if "lora_B" in n else lora.grads[n]
+        e = rel_err(gpu, pr[n].grad)
+        worst = max(worst, e)
+        assert e < 4e-2, (n, e)
+    assert len(names) == 14 and worst > 0
