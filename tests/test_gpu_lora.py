@@ -269,7 +269,13 @@ def test_mini_lora_dropout_matches_oracle(dev):
         assert rel_err(got, pr[n].grad) < 6e-2, n
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (5861, 4096, 4096), (3000, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [
+    (700, 512, 256),          # a handful of 256-row tiles
+    (5861, 4096, 4096),       # the o-proj dgrad at the LoRA batch: 192-row tiles, 496 = two waves
+    (3000, 1024, 4096),
+    (4500, 4096, 256),        # 192-row tiles with a re-cut tail (384 = 256 + 128 -> 192x128 halves)
+    (5861, 28672, 128),       # 256-row tiles with a re-cut tail (2576 = 10 x 256 + 16 -> 256x128 halves)
+])
 def test_gemm_masked_pair_equals_gemm_plus_lora_dx(dev, M, N, K):
     """dx = dy.W + keep*(u.A)/(1-p) in one GEMM (mask applied to the LoRA accumulators in place) against the
     two-kernel path; the mask bits must be the very same (forward used them), the values agree to bf16 rounding."""
