@@ -58,6 +58,13 @@ template <int D> __device__ __forceinline__ int slot_v(int r, int c) {
   if constexpr (D == 128) return c ^ ((r & 3) << 2); else return c ^ (((r >> 1) & 1) << 2);
 }
 
+// Head index of the j-th workgroup of a (block, clip) segment.  Consecutive workgroups land on consecutive XCDs
+// (id mod 8), each with its own L2: with Hq a multiple of 8, XCD x gets q-heads x*Hq/8 .. - i.e. the q-heads of a
+// GQA group (which stream the same K/V tiles at the same time) share one L2 instead of fetching them 4 times.
+__device__ __forceinline__ int xcd_head(int j, int Hq) {
+  return (Hq & 7) == 0 ? (j & 7) * (Hq >> 3) + (j >> 3) : j;
+}
+
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int CPR = D / 8;             // 16-byte chunks per row
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   // (the most key tiles) is dispatched before any of the previous one, for all heads and clips
   const int per_qb = p.Hq * p.B, slot = blockIdx.x / per_qb;
   const int qb = CAUSAL ? (nqb - 1 - slot) : slot;
-  const int hq = (blockIdx.x % per_qb) % p.Hq, b = (blockIdx.x % per_qb) / p.Hq;
+  const int hq = xcd_head((blockIdx.x % per_qb) % p.Hq, p.Hq), b = (blockIdx.x % per_qb) / p.Hq;
   const int hkv = hq / (p.Hq / p.Hkv);
   const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;                 // tokens of this clip
   const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;            // its first row
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p, bf
   // 1-D grid ordered by weight: every workgroup of key block 0 (the most query blocks under the causal mask) is
   // dispatched before any of key block 1, and so on - longest jobs first over the whole launch
   const int per_kb = p.Hq * p.B;
-  const int kb = blockIdx.x / per_kb, hq = (blockIdx.x % per_kb) % p.Hq, b = (blockIdx.x % per_kb) / p.Hq;
+  const int kb = blockIdx.x / per_kb, hq = xcd_head((blockIdx.x % per_kb) % p.Hq, p.Hq), b = (blockIdx.x % per_kb) / p.Hq;
   const int gsz = p.Hq / p.Hkv;
   const int hkv = hq / gsz;
   const int k0 = kb * BK_KEYS;
@@ -855,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnDqArgs p) {
   // (the most key tiles) is dispatched before any of the previous one, for all heads and clips
   const int per_qb = p.Hq * p.B, slot = blockIdx.x / per_qb;
   const int qb = CAUSAL ? (nqb - 1 - slot) : slot;
-  const int hq = (blockIdx.x % per_qb) % p.Hq, b = (blockIdx.x % per_qb) / p.Hq;
+  const int hq = xcd_head((blockIdx.x % per_qb) % p.Hq, p.Hq), b = (blockIdx.x % per_qb) / p.Hq;
   const int hkv = hq / (p.Hq / p.Hkv);
   const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
   const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
