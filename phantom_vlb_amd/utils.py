@@ -19,12 +19,10 @@ except Exception:  # pragma: no cover
 
 
 def get_hrf_weight(time_diff: float) -> float:
-    """src/utils.py:14-37 - preprocessing-time helper (Glover HRF via nilearn). Needs nilearn."""
-    import numpy as np
-    from nilearn.glm.first_level import compute_regressor  # noqa: WPS433 (optional dependency)
-    reg, _ = compute_regressor(exp_condition=np.array([[0], [1], [1]]), hrf_model="glover",
-                               frame_times=np.array([0.0, time_diff]))
-    return reg[-1, 0]
+    """src/utils.py:14-37 - preprocessing-time helper (Glover HRF).  nilearn when importable, else the
+    restatement of its algorithm in phantom_vlb_amd/episodes.py (unpinned)."""
+    from .episodes import get_hrf_weight as _impl
+    return _impl(time_diff)
 
 
 class HRFConvolveLayer:
