@@ -61,6 +61,21 @@ int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int l
                   const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
                   const void* W2, int ldw2, int K2, void* stream);
 
+/* Same contraction with a caller-owned scratch buffer (>= vlb_gemm_workspace_bytes(), 16-byte aligned, may be shared
+ * by every GEMM issued on one stream).  With it the tiles of a partial last wave (tile count not a multiple of the
+ * 256 CUs) are each cut into 2-8 contiguous K ranges that run on otherwise idle CUs; fp32 partial tiles go through
+ * the workspace and are summed in a fixed order (deterministic for a given shape; the fp32 summation order of those
+ * tiles differs from the unsplit kernel's).  ws == NULL behaves exactly like vlb_gemm_bf16. */
+int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                     const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                     const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream);
+int64_t vlb_gemm_workspace_bytes(void);
+/* How a long-K GEMM (K + K2 >= 4096, N % 256 == 0) is cut on the four-wave kernel: tile rows (192|256) * 1000 +
+ * tail mode * 100 + K splits; tail mode 0 = whole tiles, 1 = partial wave re-cut into 256x128 halves, 2 = split-K
+ * through the workspace.  0 for other shapes.  with_workspace: 0 none, 1 vlb_gemm_bf16_ws, 3 vlb_gemm_bf16_masked_pair_ws
+ * (K2 = 64).  Pure host arithmetic (tests). */
+int vlb_gemm_plan(int M, int N, int K, int K2, int with_workspace);
+
 /* Which kernel vlb_gemm_bf16 picks for a shape: 0 = generic 64x64, 1 = 256x256, 2 = 256x128. */
 /* LoRA backward through dropout in ONE GEMM (peft: dx = dy.W + dropout_mask * (u.A) / (1-p)):
  *   C[M,N] = A[M,K].W[N,K]^T + keep(m,n)/(1-p) * (A2[M,64].W2[N,64]^T)
@@ -70,6 +85,11 @@ int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int l
 int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                               const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
                               void* stream);
+
+/* ... with the split-K workspace of vlb_gemm_bf16_ws (the masked pair rides in the first K range). */
+int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                 const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                                 void* ws, int64_t ws_bytes, void* stream);
 
 int vlb_gemm_kernel_choice(int M, int N, int K, int K2);
 

@@ -24,6 +24,9 @@ SIGNATURES = {
     "vlb_abi_version": [],
     "vlb_last_error": [],
     "vlb_gemm_bf16": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P],
+    "vlb_gemm_bf16_ws": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P, L, P],
+    "vlb_gemm_workspace_bytes": [],
+    "vlb_gemm_plan": [I, I, I, I, I],
     "vlb_gemm_kernel_choice": [I, I, I, I],
     "vlb_transpose_bf16": [P, P, I, I, P],
     "vlb_attention_fwd": [P, I, P, I, P, I, P, I, P, P, I, I, I, I, I, I, F, P, P],
@@ -49,6 +52,7 @@ SIGNATURES = {
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P, I, P],
     "vlb_gemm_bf16_masked_pair": [P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P],
+    "vlb_gemm_bf16_masked_pair_ws": [P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P, L, P],
     "vlb_wgrad_u_ws_floats": [I, I],
     "vlb_wgrad_skinny_u": [P, I, P, I, P, P, I, I, F, F, P, F, P, I, P, P],
     "vlb_transpose16_scatter": [P, I, P],
@@ -62,7 +66,8 @@ SIGNATURES = {
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
-_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64}
+_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
+             "vlb_gemm_workspace_bytes": c_int64}
 
 
 class VlbError(RuntimeError):

@@ -32,22 +32,17 @@ struct GemmArgs {
   // masked second pair (LoRA backward through dropout): C = A.W^T + keep(m,n)/(1-p) * (A2.W2^T), keep from the
   // counter hash of lora.hip (fast 32-bit path): bits(m, n) = lowbias32((m*(N/2) + n/2) ^ key), 16 bits per column
   uint32_t drop_thresh, drop_key; float drop_scale;
+  // split-K tail launch: the tiles of a partial last wave are each cut into k_splits contiguous K ranges, one
+  // workgroup per (split, tile); raw fp32 accumulators go to ws[split][tile][wave][i][j][lane][4] and
+  // gemm_splitk_reduce_kernel sums the splits in a fixed order and applies the epilogue
+  float* ws; int k_splits, tail_tiles;
 };
 
 // blockIdx -> (m0, n0).  XCD-aware: blocks b and b+8 share an XCD, so each XCD gets a contiguous run of the
 // launch's tiles; tiles are walked in bands of GROUP_M row-tiles so concurrently resident tiles share A/W
 // panels in that XCD's L2.  The order is defined on the full parent grid, so a GEMM can be cut into several
 // launches (full waves with 256x256 tiles + a partial last wave re-tiled 256x128) at any tile index.
-__device__ __forceinline__ void map_tile(const GemmArgs& p, int BM, int BN, int& m0, int& n0) {
-  const int nblk = gridDim.x;
-  int pid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
-    pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-  }
-  int sub = 0;
-  if (p.split_n > 1) { sub = pid % p.split_n; pid /= p.split_n; }
-  pid += p.tile0;
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int pid, int sub, int BM, int BN, int& m0, int& n0) {
   constexpr int GROUP_M = 4;
   const int band = GROUP_M * p.tiles_n;
   const int g0 = (pid / band) * GROUP_M;
@@ -56,6 +51,23 @@ __device__ __forceinline__ void map_tile(const GemmArgs& p, int BM, int BN, int&
   const int tn = (pid % band) / gsz;
   m0 = tm * BM;
   n0 = (tn * p.split_n + sub) * BN;
+}
+
+// blocks b and b+8 run on the same XCD: give each XCD a contiguous run of the launch's work items
+__device__ __forceinline__ int xcd_remap_pid() {
+  const int nblk = gridDim.x, pid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// returns the K split of this workgroup (0 unless the launch is a split-K tail)
+__device__ __forceinline__ int map_tile(const GemmArgs& p, int BM, int BN, int& m0, int& n0) {
+  int pid = xcd_remap_pid();
+  int sub = 0, ks = 0;
+  if (p.split_n > 1) { sub = pid % p.split_n; pid /= p.split_n; }
+  if (p.k_splits > 1) { ks = pid / p.tail_tiles; pid -= ks * p.tail_tiles; }   // split-major: an XCD's run shares one K range
+  tile_coords(p, pid + p.tile0, sub, BM, BN, m0, n0);
+  return ks;
 }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -517,12 +529,41 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
                : "v"(__builtin_bit_cast(i32x4_t, a)), "v"(__builtin_bit_cast(i32x4_t, b)));
 }
 
+// epilogue of one 16x16 accumulator fragment: lane holds C[m][n .. n+3]
+__device__ __forceinline__ void w4_store_frag(const GemmArgs& p, f32x4 v, int m, int n) {
+  if (p.bias) {
+    const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+  }
+  if (p.act != VLB_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+  }
+  if (p.residual) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+}
+// SWIGLU_PAIR: fragments j (gate) and j+1 (up) of the interleaved weight -> silu(gate)*up at output column n
+__device__ __forceinline__ void w4_store_swiglu(const GemmArgs& p, const f32x4& g, const f32x4& u, int m, int n) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(g[e]) * u[e]);
+  *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+}
+
 // NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
 // of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.  MT = 6: 192-row tiles (wave
 // block 96 rows), picked by the host when they quantise the row count into fewer, fuller waves of tiles.
 // MASKED: the second operand pair (one K-tile, K2 = 64) runs FIRST, the accumulators are then multiplied by the
 // dropout keep mask / (1-p) in place, and the main K loop continues on top - dx = dy.W + keep*(u.A)/(1-p) in one GEMM.
-template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false>
+template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
   constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
@@ -536,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int m0, n0;
-  map_tile(p, BM, BN, m0, n0);
+  const int ksplit = map_tile(p, BM, BN, m0, n0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -552,25 +593,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
   const int rowA = m0 + r0, rowW = n0 + r0;
   const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
-  const int nk = p.K / BK + p.K2 / BK;
+  const int nk_all = p.K / BK + p.K2 / BK;
+  // split-K tail: this workgroup walks K-tiles [kt_lo, kt_lo + nk) of the concatenated (pair 1 | pair 2) sequence
+  const int kt_lo = SPLITK ? (int)((int64_t)ksplit * nk_all / p.k_splits) : 0;
+  const int nk = SPLITK ? (int)((int64_t)(ksplit + 1) * nk_all / p.k_splits) - kt_lo : nk_all;
 
   // LDS-DMA sources = uniform base (SGPR pair, advanced 128 B per K-tile) + a per-instruction 32-bit
   // byte offset held in a VGPR: the loop issues each global_load_lds with no address arithmetic at all.
   // The offsets are rebuilt once when the K loop crosses into the second operand pair (A2, W2).
   uint32_t offA[A_LD], offW[B_LD];
   const char* curA; const char* curW;
-  auto set_operands = [&](const bf16* A_, const bf16* W_, int lda_, int ldw_) {
+  auto set_operands = [&](const bf16* A_, const bf16* W_, int lda_, int ldw_, int kt_in_pair) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i)
       offA[i] = ((uint32_t)min(rowA + 32 * i, p.M - 1) * (uint32_t)lda_ + (uint32_t)colb) * 2u;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) offW[j] = ((uint32_t)(rowW + 32 * j) * (uint32_t)ldw_ + (uint32_t)colb) * 2u;
-    curA = reinterpret_cast<const char*>(A_);
-    curW = reinterpret_cast<const char*>(W_);
+    curA = reinterpret_cast<const char*>(A_) + (int64_t)kt_in_pair * ROW_BYTES;
+    curW = reinterpret_cast<const char*>(W_) + (int64_t)kt_in_pair * ROW_BYTES;
   };
-  auto select = [&](int kt) {           // call with consecutive kt: positions the bases on K-tile kt
-    if (kt == 0) { if (MASKED) set_operands(p.A2, p.W2, p.lda2, p.ldw2); else set_operands(p.A, p.W, p.lda, p.ldw); }
-    else if (kt == nk1) { if (MASKED) set_operands(p.A, p.W, p.lda, p.ldw); else set_operands(p.A2, p.W2, p.lda2, p.ldw2); }
+  auto select = [&](int rel) {          // call with consecutive rel = 0, 1, ..: positions the bases on K-tile kt_lo + rel
+    const int kt = SPLITK ? rel + kt_lo : rel;
+    if (rel == 0) {
+      const bool second = SPLITK && kt >= nk1;
+      if (MASKED != second) set_operands(p.A2, p.W2, p.lda2, p.ldw2, second ? kt - nk1 : kt);
+      else set_operands(p.A, p.W, p.lda, p.ldw, second ? kt - nk1 : kt);
+    }
+    else if (kt == nk1) { if (MASKED) set_operands(p.A, p.W, p.lda, p.ldw, 0); else set_operands(p.A2, p.W2, p.lda2, p.ldw2, 0); }
     else { curA += ROW_BYTES; curW += ROW_BYTES; }
   };
   auto dma = [&](int buf, int i) {     // instruction i of the selected tile (0..A_LD-1: A, then W)
@@ -678,7 +727,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   using T_ = std::true_type; using F_ = std::false_type;
   int kt = 0;
   if constexpr (MASKED) {
-    // K-tile 0 = the LoRA pair u.A (host guarantees K2 == 64 and nk >= 3); then keep/(1-p) on the accumulators
+    // K-tile 0 = the LoRA pair u.A (host guarantees K2 == 64 and nk >= 3); then keep/(1-p) on the accumulators.
+    // In a split-K tail only the first K range holds the pair: the others run their first main tile here and the
+    // mask degenerates to keep-all x 1.0 (same straight-line code, no branch around the pinned accumulators).
+    const uint32_t m_thresh = (SPLITK && ksplit != 0) ? 0u : p.drop_thresh;
+    const float m_scale = (SPLITK && ksplit != 0) ? 1.f : p.drop_scale;
     tile(0, T_{}, T_{});
     kt = 1;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -700,8 +753,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         for (int q = 0; q < 2; ++q) {
           uint32_t h = (rb + pair0 + q) ^ p.drop_key;
           h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;      // lowbias32
-          v[2 * q] = (h & 0xffffu) >= p.drop_thresh ? v[2 * q] * p.drop_scale : 0.f;
-          v[2 * q + 1] = (h >> 16) >= p.drop_thresh ? v[2 * q + 1] * p.drop_scale : 0.f;
+          v[2 * q] = (h & 0xffffu) >= m_thresh ? v[2 * q] * m_scale : 0.f;
+          v[2 * q + 1] = (h >> 16) >= m_thresh ? v[2 * q + 1] * m_scale : 0.f;
         }
         acc[i][j] = v;
         // straight back into its AGPR tuple, one tile at a time: keeps the VGPR live set (fragments of the next
@@ -727,19 +780,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #undef W4_FENCE
 #undef W4_BARRIER
 
+  if constexpr (SPLITK) {
+    // work item (= remapped block id) ksplit * tail_tiles + tile owns one [4 waves][MT][NT][64 lanes][4] slab
+    float* wt = p.ws + ((int64_t)xcd_remap_pid() * 4 + wave) * (MT * NT * 256);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<f32x4*>(wt + ((i * NT + j) * 64 + lane) * 4) = acc[i][j];
+    return;
+  }
   if (p.act == VLB_ACT_SWIGLU_PAIR) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * TM + i * 16 + fr;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int n = (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4;
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(acc[i][j][e]) * acc[i][j + 1][e]);
-        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
-      }
+      for (int j = 0; j < NT; j += 2) w4_store_swiglu(p, acc[i][j], acc[i][j + 1], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4);
     }
     return;
   }
@@ -748,37 +805,45 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * TN + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
-      }
-      if (p.act != VLB_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-      }
-      if (p.residual) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
-    }
+    for (int j = 0; j < NT; ++j) w4_store_frag(p, acc[i][j], m, n0 + wn * TN + j * 16 + fq * 4);
   }
 }
 
-template <int NT, int ABL, int MT = 8, bool MASKED = false>
+// Second half of a split-K tail: block (tile, i) sums row-tile i of every wave's accumulators over the splits in
+// a fixed order (deterministic) and applies the four-wave kernel's epilogue with the same thread <-> element map.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
+  constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
+  const int tl = blockIdx.x / MT, i = blockIdx.x % MT;
+  int m0, n0;
+  tile_coords(p, p.tile0 + tl, 0, BM, BN, m0, n0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+  f32x4 v[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.k_splits; ++s) {
+    const float* wt = p.ws + ((int64_t)(s * p.tail_tiles + tl) * 4 + wave) * (MT * NT * 256);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) v[j] += *reinterpret_cast<const f32x4*>(wt + ((i * NT + j) * 64 + lane) * 4);
+  }
+  const int m = m0 + wm * TM + i * 16 + fr;
+  if (m >= p.M) return;
+  if (p.act == VLB_ACT_SWIGLU_PAIR) {
+#pragma unroll
+    for (int j = 0; j < NT; j += 2) w4_store_swiglu(p, v[j], v[j + 1], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) w4_store_frag(p, v[j], m, n0 + wn * TN + j * 16 + fq * 4);
+}
+
+template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
@@ -786,7 +851,20 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+// partial last wave as a split-K pair of launches: a = the launch of the tail's parent tiles (tile0, tail_tiles,
+// k_splits, ws set by the caller)
+template <int MT, bool MASKED = false>
+int launch_w4_splitk(GemmArgs& a, hipStream_t s) {
+  a.split_n = 1;
+  a.grid = a.k_splits * a.tail_tiles;
+  int rc = launch_w4<8, 0, MT, MASKED, true>(a, s);
+  if (rc != VLB_OK) return rc;
+  hipLaunchKernelGGL((gemm_splitk_reduce_kernel<MT, 8>), dim3(a.tail_tiles * MT), dim3(256), 0, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -796,6 +874,34 @@ int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong wave groups,
                         // when the cost model prefers them; 5 (A/B): like 3 but always 192-row tiles for long K
 int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
+int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
+
+// How the partial last wave of `tiles` tiles (nk K-tiles each) is run.  Costs are in units of one full wave of
+// tiles: whole tiles 1.0; re-cut 256x128 halves 0.62 (measured 0.6-0.8); split-K 1/s plus ~16 K-tiles' worth
+// (25-40 us measured) of fixed work (fp32 slab store, second launch, reduce).
+struct TailPlan { int mode; int splits; double cost; };       // mode 0: none / whole tiles, 1: halves, 2: split-K
+inline TailPlan plan_tail(int tiles, int nk, bool ws_ok, bool allow_halves = true) {
+  const int cus = 256, r = tiles % cus;
+  TailPlan t{0, 1, r == 0 ? 0.0 : 1.0};
+  if (r == 0 || tiles <= cus) return t;
+  if (allow_halves && g_tail_split && r <= cus * 5 / 8) t = TailPlan{1, 1, 0.62};
+  if (ws_ok && g_tail_splitk) {
+    int sp = cus / r; if (sp > 8) sp = 8;
+    while (sp > 1 && nk / sp < 8) --sp;
+    const double c = 1.0 / sp + 16.0 / nk;
+    if (sp >= 2 && c < t.cost) t = TailPlan{2, sp, c};
+  }
+  return t;
+}
+// 192- or 256-row tiles for an [M, N] output (N % 256 == 0) on the four-wave kernel: cost = waves x tile rows, the
+// smaller tile charged 2 % more; returns true for 192 rows.  Also hands back both tail plans.
+inline bool plan_rows(int M, int N, int Ktot, bool ws_ok, TailPlan& p256, TailPlan& p192, bool splitk256 = true) {
+  const int cus = 256, tn = N / 256, nk = Ktot / BK;
+  const int tiles = ((M + 255) / 256) * tn, tiles192 = ((M + 191) / 192) * tn;
+  p256 = plan_tail(tiles, nk, ws_ok && splitk256); p192 = plan_tail(tiles192, nk, ws_ok);
+  const double c256 = (tiles / cus + p256.cost) * 256.0, c192 = (tiles192 / cus + p192.cost) * 192.0 * 1.02;
+  return tiles > cus && c192 < 0.97 * c256;
+}
 
 template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3, int ABL = 0>
 int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
@@ -910,10 +1016,30 @@ extern "C" int vlb_gemm_kernel_choice(int M, int N, int K, int K2) {
   return 0;
 }
 
+// Tuning / test aid: how a long-K GEMM on the four-wave kernel is cut: rows*1000 + tail mode*100 + K splits
+// (tail mode 0 whole tiles, 1 re-cut halves, 2 split-K).
+extern "C" int vlb_gemm_plan(int M, int N, int K, int K2, int with_workspace) {
+  if (N % 256 != 0 || K + K2 < 4096) return 0;
+  TailPlan p256, p192;
+  const bool use192 = plan_rows(M, N, K + K2, (with_workspace & 1) != 0, p256, p192, !(with_workspace & 2));     // bit 1: masked-pair rules
+  const TailPlan& t = use192 ? p192 : p256;
+  return (use192 ? 192 : 256) * 1000 + t.mode * 100 + t.splits;
+}
+
+extern "C" int64_t vlb_gemm_workspace_bytes(void) { return 256ll * 256 * 256 * 4; }   // <= 256 work items x one 256x256 fp32 tile
+
 extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                              const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
                              const void* W2, int ldw2, int K2, void* stream) {
+  return vlb_gemm_bf16_ws(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, A2, lda2, W2, ldw2, K2, nullptr, 0, stream);
+}
+
+extern "C" int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                                const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream) {
   VLB_REQUIRE(A && W && C, "gemm: null operand");
+  VLB_REQUIRE(!ws || ((uintptr_t)ws % 16) == 0, "gemm: workspace must be 16-byte aligned");
+  const bool ws_ok = ws && ws_bytes >= vlb_gemm_workspace_bytes();
   VLB_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VLB_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
   VLB_REQUIRE(lda >= K && ldw >= K && (ldc >= N || (act == VLB_ACT_SWIGLU_PAIR && ldc >= N / 2)), "gemm: leading dimension smaller than row");
@@ -934,6 +1060,7 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0;
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
@@ -954,25 +1081,34 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
     {
       const bool fits32 = (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) &&
                           (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
-      auto waves = [&](int t, bool& split) {
-        const int full = t / cus, r = t % cus;
-        split = g_tail_split && t > cus && r != 0 && r <= cus * 5 / 8;
-        return (double)full + (r == 0 ? 0.0 : (split ? 0.62 : 1.0));
-      };
-      bool s256, s192;
+      const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
       const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
-      const double c256 = waves(tiles, s256) * 256.0, c192 = waves(tiles192, s192) * 192.0 * 1.02;   // 2 %: smaller tile
-      if ((g_variant == 3 || g_variant == 5) && g_force_tile == 0 && fits32 && K + K2 >= 4096 && tiles > cus &&
-          (g_variant == 5 || c192 < 0.97 * c256)) {
+      TailPlan p256, p192;
+      const bool use192 = plan_rows(M, N, K + K2, ws_ok && w4, p256, p192);
+      if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || use192)) {
         GemmArgs hi = a;
         hi.tiles_m = tm192; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
         const int rem192 = tiles192 % cus;
-        hi.grid = s192 ? tiles192 - rem192 : tiles192;
+        hi.grid = p192.mode ? tiles192 - rem192 : tiles192;
         int rc = launch_w4<8, 0, 6>(hi, s);
-        if (rc != VLB_OK || !s192) return rc;
+        if (rc != VLB_OK || !p192.mode) return rc;
         GemmArgs lo = hi;
-        lo.tile0 = tiles192 - rem192; lo.split_n = 2; lo.grid = 2 * rem192;
+        lo.tile0 = tiles192 - rem192;
+        if (p192.mode == 2) {
+          lo.ws = (float*)ws; lo.k_splits = p192.splits; lo.tail_tiles = rem192;
+          return launch_w4_splitk<6>(lo, s);
+        }
+        lo.split_n = 2; lo.grid = 2 * rem192;
         return launch_w4<4, 0, 6>(lo, s);
+      }
+      if (w4 && g_force_tile == 0 && p256.mode == 2) {
+        GemmArgs hi = a;
+        hi.tiles_m = tm; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1; hi.grid = tiles - rem;
+        int rc = launch_w4<8, 0, 8>(hi, s);
+        if (rc != VLB_OK) return rc;
+        GemmArgs lo = hi;
+        lo.tile0 = tiles - rem; lo.ws = (float*)ws; lo.k_splits = p256.splits; lo.tail_tiles = rem;
+        return launch_w4_splitk<8>(lo, s);
       }
     }
     if (g_tail_split && tiles > cus && rem != 0 && rem <= cus * 5 / 8) {
@@ -1004,6 +1140,14 @@ inline uint32_t lowbias32_h(uint32_t x) {
 extern "C" int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                                          const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
                                          void* stream) {
+  return vlb_gemm_bf16_masked_pair_ws(A, lda, W, ldw, C, ldc, M, N, K, A2, lda2, W2, ldw2, drop_p, seed, nullptr, 0, stream);
+}
+
+extern "C" int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                                            const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                                            void* ws, int64_t ws_bytes, void* stream) {
+  VLB_REQUIRE(!ws || ((uintptr_t)ws % 16) == 0, "gemm_masked_pair: workspace must be 16-byte aligned");
+  const bool ws_ok = ws && ws_bytes >= vlb_gemm_workspace_bytes();
   VLB_REQUIRE(A && W && C && A2 && W2, "gemm_masked_pair: null operand");
   VLB_REQUIRE(M > 0 && N % 256 == 0 && K >= 128 && K % 64 == 0, "gemm_masked_pair: needs N %% 256 == 0, K %% 64 == 0, K >= 128 (N=%d K=%d)", N, K);
   VLB_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && lda >= K && ldw >= K && lda2 >= 64 && ldw2 >= 64 &&
@@ -1021,32 +1165,33 @@ extern "C" int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, 
   a.M = M; a.N = N; a.K = K; a.K2 = 64;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = VLB_ACT_NONE; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
   a.drop_key = lowbias32_h(seed);
   a.drop_scale = 1.f / (1.f - drop_p);
   hipStream_t s = as_stream(stream);
-  // same wave-quantisation choice as vlb_gemm_bf16 (256- or 192-row tiles, re-cut partial wave)
+  // same wave-quantisation choice as vlb_gemm_bf16 (256- or 192-row tiles; partial wave re-cut or split along K)
   const int cus = 256, tn = N / 256;
-  auto waves = [&](int t_, bool& split) {
-    const int full = t_ / cus, r = t_ % cus;
-    split = g_tail_split && t_ > cus && r != 0 && r <= cus * 5 / 8;
-    return (double)full + (r == 0 ? 0.0 : (split ? 0.62 : 1.0));
-  };
-  bool s256, s192;
-  const int tm256 = (M + 255) / 256, tm192 = (M + 191) / 192;
-  const int t256 = tm256 * tn, t192 = tm192 * tn;
-  const double c256 = waves(t256, s256) * 256.0, c192 = waves(t192, s192) * 192.0 * 1.02;
-  const bool use192 = t256 > cus && c192 < 0.97 * c256;
-  const int tiles = use192 ? t192 : t256, rem = tiles % cus;
-  const bool split = use192 ? s192 : s256;
+  TailPlan p256, p192;
+  // (no split-K for the 256-row masked kernel: with 64 accumulator tiles + the mask temporaries the register
+  // allocator starts rotating accumulator tuples behind the asm MFMAs; 192-row tiles are fine)
+  const bool use192 = plan_rows(M, N, K + 64, ws_ok, p256, p192, false);
+  const TailPlan& tp = use192 ? p192 : p256;
+  const int tm = use192 ? (M + 191) / 192 : (M + 255) / 256;
+  const int tiles = tm * tn, rem = tiles % cus;
   GemmArgs hi = a;
-  hi.tiles_m = use192 ? tm192 : tm256; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
-  hi.grid = split ? tiles - rem : tiles;
+  hi.tiles_m = tm; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
+  hi.grid = tp.mode ? tiles - rem : tiles;
   int rc = use192 ? launch_w4<8, 0, 6, true>(hi, s) : launch_w4<8, 0, 8, true>(hi, s);
-  if (rc != VLB_OK || !split) return rc;
+  if (rc != VLB_OK || !tp.mode) return rc;
   GemmArgs lo = hi;
-  lo.tile0 = tiles - rem; lo.split_n = 2; lo.grid = 2 * rem;
+  lo.tile0 = tiles - rem;
+  if (tp.mode == 2) {
+    lo.ws = (float*)ws; lo.k_splits = tp.splits; lo.tail_tiles = rem;
+    return launch_w4_splitk<6, true>(lo, s);
+  }
+  lo.split_n = 2; lo.grid = 2 * rem;
   return use192 ? launch_w4<4, 0, 6, true>(lo, s) : launch_w4<4, 0, 8, true>(lo, s);
 }
 
@@ -1055,6 +1200,7 @@ extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;
   g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
+  g_tail_splitk = (variant & 0x200) ? 0 : 1;   // bit 9 disables the split-K tail (A/B)
 }
 
 extern "C" int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {

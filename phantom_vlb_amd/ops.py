@@ -56,6 +56,22 @@ def disable_gemm_probe():
     _probe = None
 
 
+_gemm_ws = {}
+split_k_tails = True        # False: never pass the workspace (every output element then sums K in one fixed order
+                            # whatever the row count - what the packed == dense bit-identity tests rely on)
+
+
+def _gemm_workspace(device):
+    """One scratch buffer per (device, stream) for the split-K tails of vlb_gemm_bf16_ws."""
+    if not split_k_tails:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = _gemm_ws[key] = torch.empty(lib.vlb_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=None):
     """out[M,N] = act(a[M,K] @ w[N,K]^T + a2 @ w2^T + bias) + residual   (all bf16, fp32 accumulate)."""
     _dev(a)
@@ -74,10 +90,12 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
         _probe.M = M
         _probe.pairs.append((e0, e1))
         e0.record()
-    check(lib.vlb_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                            M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
-                            _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
-                            w2.stride(0) if w2 is not None else 0, K2, _stream()), "vlb_gemm_bf16")
+    ws = _gemm_workspace(a.device) if K + K2 >= 4096 and M * N > 256 * 192 * 256 else None    # more than one wave of tiles
+    check(lib.vlb_gemm_bf16_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                               M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
+                               _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
+                               w2.stride(0) if w2 is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
+                               _stream()), "vlb_gemm_bf16")
     if timed:
         e1.record()
     return out
@@ -96,9 +114,11 @@ def gemm_masked_pair(a, w, a2, w2, p, seed, out=None):
     assert w.shape[1] == K and a2.shape[0] == M and w2.shape[0] == N and a2.shape[1] >= 64 and w2.shape[1] >= 64
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
-    check(lib.vlb_gemm_bf16_masked_pair(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                                        M, N, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), float(p),
-                                        int(seed) & 0xFFFFFFFF, _stream()), "vlb_gemm_bf16_masked_pair")
+    ws = _gemm_workspace(a.device) if K + 64 >= 4096 and M * N > 256 * 192 * 256 else None
+    check(lib.vlb_gemm_bf16_masked_pair_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                           M, N, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), float(p),
+                                           int(seed) & 0xFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream()),
+          "vlb_gemm_bf16_masked_pair")
     return out
 
 

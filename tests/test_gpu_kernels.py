@@ -61,9 +61,15 @@ def test_gemm_long_k_and_tail_split(dev, M, N, K, K2):
     assert rel_err(out, y) < 6e-3
     # a row's result must not depend on how many rows the call has (packed layouts rely on it): the same
     # rows through a differently tiled launch are bit-identical
-    half = ops.gemm(a[: M // 2 + 3], w, bias=bias, residual=res[: M // 2 + 3], act=ops.ACT_SILU,
-                    a2=None if a2 is None else a2[: M // 2 + 3], w2=w2)
-    assert torch.equal(half, out[: M // 2 + 3])
+    # (with the split-K tails off: they change the fp32 summation order of the tiles of a partial wave)
+    ops.split_k_tails = False
+    try:
+        full = ops.gemm(a, w, bias=bias, residual=res, act=ops.ACT_SILU, a2=a2, w2=w2)
+        half = ops.gemm(a[: M // 2 + 3], w, bias=bias, residual=res[: M // 2 + 3], act=ops.ACT_SILU,
+                        a2=None if a2 is None else a2[: M // 2 + 3], w2=w2)
+    finally:
+        ops.split_k_tails = True
+    assert torch.equal(half, full[: M // 2 + 3])
 
 
 def test_gemm_swiglu_pair_long_k_tail_split(dev):
@@ -427,3 +433,46 @@ def test_head_fwd_bwd(dev, B, S, E, V, drop):
         assert rel_err(head.grads[n], pr[n].grad) < 1e-2, n
     assert rel_err(dh.view(B, S, E), hr.grad) < 1.5e-2
     assert (dh.view(B, S, E)[:, : S // 3] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K,K2,plan", [(5015, 4096, 4096, 0, 256204), (2573, 6144, 4096, 0, 192203),
+                                            (2600, 6144, 4096, 64, 192203), (5861, 4096, 14336, 64, 256202)])
+def test_gemm_split_k_tail(dev, M, N, K, K2, plan):
+    """Partial last wave cut along K through the workspace (vlb_gemm_bf16_ws): same result as the unsplit kernel up
+    to fp32 summation order, deterministic, epilogue (bias / activation / residual / second pair) intact."""
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd._lib import lib
+    assert lib.vlb_gemm_plan(M, N, K, K2, 1) == plan
+    a, w = _r(M, K, dev=dev), _r(N, K, dev=dev, scale=0.05)
+    bias, res = _r(N, dev=dev), _r(M, N, dev=dev)
+    a2 = w2 = None
+    ref = a.float() @ w.float().t()
+    if K2:
+        a2, w2 = _r(M, K2, dev=dev, seed=3), _r(N, K2, dev=dev, scale=0.05, seed=4)
+        ref = ref + a2.float() @ w2.float().t()
+    y = F.silu(ref + bias.float()) + res.float()
+    assert ops.split_k_tails
+    out = ops.gemm(a, w, bias=bias, residual=res, act=ops.ACT_SILU, a2=a2, w2=w2)
+    assert rel_err(out, y) < 6e-3
+    again = ops.gemm(a, w, bias=bias, residual=res, act=ops.ACT_SILU, a2=a2, w2=w2)
+    assert torch.equal(out, again)
+    ops.split_k_tails = False
+    try:
+        plain = ops.gemm(a, w, bias=bias, residual=res, act=ops.ACT_SILU, a2=a2, w2=w2)
+    finally:
+        ops.split_k_tails = True
+    assert rel_err(plain, y) < 6e-3
+    assert not torch.equal(plain, out)              # the tail really went through the split path
+    assert rel_err(out, plain.float()) < 4e-3
+
+
+def test_gemm_split_k_tail_swiglu_pair(dev):
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd._lib import lib
+    M, ff, K = 5015, 2048, 4096
+    assert lib.vlb_gemm_plan(M, 2 * ff, K, 0, 1) == 256204
+    a = _r(M, K, dev=dev)
+    wg, wu = _r(ff, K, dev=dev, scale=0.03, seed=1), _r(ff, K, dev=dev, scale=0.03, seed=2)
+    out = ops.gemm(a, ops.interleave_gate_up(wg, wu), act=ops.ACT_SWIGLU_PAIR)
+    ref = F.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
+    assert rel_err(out, ref) < 8e-3

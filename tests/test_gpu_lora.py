@@ -275,6 +275,8 @@ def test_mini_lora_dropout_matches_oracle(dev):
     (3000, 1024, 4096),
     (4500, 4096, 256),        # 192-row tiles with a re-cut tail (384 = 256 + 128 -> 192x128 halves)
     (5861, 28672, 128),       # 256-row tiles with a re-cut tail (2576 = 10 x 256 + 16 -> 256x128 halves)
+    (5009, 4096, 4096),       # 256-row tiles: the masked kernel keeps the re-cut halves here (no split-K at 256 rows)
+    (2573, 6144, 4096),       # 192-row tiles, partial wave split 3 ways along K (the masked pair rides in split 0)
 ])
 def test_gemm_masked_pair_equals_gemm_plus_lora_dx(dev, M, N, K):
     """dx = dy.W + keep*(u.A)/(1-p) in one GEMM (mask applied to the LoRA accumulators in place) against the
