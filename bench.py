@@ -186,7 +186,7 @@ def main():
                        # executed FLOPs: the per-clip figure scaled by the rows actually run (conservative: the vision tower is not reduced)
                        "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense, 1),
                        "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + its 256x128 tail launch "
+            "roofline": {"bound": "mfma", "kernel": "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + the split-K launches of its partial last wave "
                          f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_bf16 call", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
