@@ -40,6 +40,7 @@ extern "C" {
 #define VLB_ACT_SILU 3       /* SE fc1, sampler */
 #define VLB_ACT_SWIGLU_PAIR 4 /* MistralMLP act_fn(gate)*up fused into the gate/up GEMM: W rows interleaved in
                                  16-row blocks [gate_b | up_b | gate_b+1 | ...]; C gets N/2 columns; no bias/residual */
+#define VLB_ACT_SWIGLU_BWD 5  /* internal: epilogue of vlb_gemm_masked_pair_swiglu_bwd */
 
 int vlb_abi_version(void);
 const char* vlb_last_error(void);
@@ -90,6 +91,15 @@ int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, int ldw, vo
 int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                                  const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
                                  void* ws, int64_t ws_bytes, void* stream);
+
+/* LoRA backward of the MLP down projection fused with the SwiGLU backward (replaces vlb_gemm_bf16_masked_pair +
+ * vlb_swiglu_bwd; MistralMLP, transformers modeling_mistral.py:41-47):
+ *   d_h[M,ff]   = dY[M,K].Wt[ff,K]^T + keep/(1-p) * (U[M,64].At[ff,64]^T)        (never written)
+ *   dgu[:, :ff] = d_h * up * silu'(gate),   dgu[:, ff:] = d_h * silu(gate)       gate = gu[:, :ff], up = gu[:, ff:]
+ * in the GEMM epilogue, from the fp32 accumulators.  Shape rules of vlb_gemm_bf16_masked_pair with N = ff. */
+int vlb_gemm_masked_pair_swiglu_bwd(const void* dY, int lddy, const void* Wt, int ldw, const void* gu, int ldgu, void* dgu,
+                                    int lddgu, int M, int ff, int K, const void* U, int ldu, const void* At, int ldat,
+                                    float drop_p, uint32_t seed, void* ws, int64_t ws_bytes, void* stream);
 
 int vlb_gemm_kernel_choice(int M, int N, int K, int K2);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "vlb_head_fwd": [P] * 19 + [I, I, I, I, F, F, P, P],
     "vlb_head_bwd": [P] * 24 + [I, I, I, I, F, F, F, F, P, I, P],
     "vlb_gemm_bf16_masked_pair": [P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P],
+    "vlb_gemm_masked_pair_swiglu_bwd": [P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P, L, P],
     "vlb_gemm_bf16_masked_pair_ws": [P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P, L, P],
     "vlb_wgrad_u_ws_floats": [I, I],
     "vlb_wgrad_skinny_u": [P, I, P, I, P, P, I, I, F, F, P, F, P, I, P, P],

@@ -531,6 +531,24 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
 
 // epilogue of one 16x16 accumulator fragment: lane holds C[m][n .. n+3]
 __device__ __forceinline__ void w4_store_frag(const GemmArgs& p, f32x4 v, int m, int n) {
+  if (p.act == VLB_ACT_SWIGLU_BWD) {
+    // v = d(silu(gate)*up) for columns n..n+3 of a [M, N = ff] product; residual = the saved [gate | up] activations
+    // (row stride ldr), C = [d gate | d up] (row stride ldc): SwiGLU backward without materialising v
+    const bf16* gp = p.residual + (int64_t)m * p.ldr + n;
+    const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(gp), u4 = *reinterpret_cast<const bf16x4*>(gp + p.N);
+    bf16x4 dg, du;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = (float)g4[e], u = (float)u4[e];
+      const float sg = sigmoid_f(g);
+      du[e] = (bf16)(v[e] * (g * sg));
+      dg[e] = (bf16)(v[e] * u * (sg * (1.f + g * (1.f - sg))));
+    }
+    bf16* cp = p.C + (int64_t)m * p.ldc + n;
+    *reinterpret_cast<bf16x4*>(cp) = dg;
+    *reinterpret_cast<bf16x4*>(cp + p.N) = du;
+    return;
+  }
   if (p.bias) {
     const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
 #pragma unroll
@@ -1143,9 +1161,29 @@ extern "C" int vlb_gemm_bf16_masked_pair(const void* A, int lda, const void* W, 
   return vlb_gemm_bf16_masked_pair_ws(A, lda, W, ldw, C, ldc, M, N, K, A2, lda2, W2, ldw2, drop_p, seed, nullptr, 0, stream);
 }
 
+static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                            const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                            void* ws, int64_t ws_bytes, void* stream, int act, const void* residual, int ldr);
+
 extern "C" int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                                             const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
                                             void* ws, int64_t ws_bytes, void* stream) {
+  return masked_pair_impl(A, lda, W, ldw, C, ldc, M, N, K, A2, lda2, W2, ldw2, drop_p, seed, ws, ws_bytes, stream, VLB_ACT_NONE, nullptr, 0);
+}
+
+extern "C" int vlb_gemm_masked_pair_swiglu_bwd(const void* dY, int lddy, const void* Wt, int ldw, const void* gu, int ldgu, void* dgu,
+                                               int lddgu, int M, int ff, int K, const void* U, int ldu, const void* At, int ldat,
+                                               float drop_p, uint32_t seed, void* ws, int64_t ws_bytes, void* stream) {
+  VLB_REQUIRE(gu && dgu, "gemm_masked_pair_swiglu_bwd: null activation pointers");
+  VLB_REQUIRE(ldgu >= 2 * ff && lddgu >= 2 * ff && ldgu % 4 == 0 && lddgu % 4 == 0 && ff % 4 == 0 && (((uintptr_t)gu | (uintptr_t)dgu) % 8) == 0,
+              "gemm_masked_pair_swiglu_bwd: [gate|up] rows must hold 2*ff columns, 8-byte aligned (ff=%d ldgu=%d lddgu=%d)", ff, ldgu, lddgu);
+  return masked_pair_impl(dY, lddy, Wt, ldw, dgu, lddgu, M, ff, K, U, ldu, At, ldat, drop_p, seed, ws, ws_bytes, stream,
+                          VLB_ACT_SWIGLU_BWD, gu, ldgu);
+}
+
+static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                            const void* A2, int lda2, const void* W2, int ldw2, float drop_p, uint32_t seed,
+                            void* ws, int64_t ws_bytes, void* stream, int act, const void* residual, int ldr) {
   VLB_REQUIRE(!ws || ((uintptr_t)ws % 16) == 0, "gemm_masked_pair: workspace must be 16-byte aligned");
   const bool ws_ok = ws && ws_bytes >= vlb_gemm_workspace_bytes();
   VLB_REQUIRE(A && W && C && A2 && W2, "gemm_masked_pair: null operand");
@@ -1161,10 +1199,10 @@ extern "C" int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* 
   GemmArgs a;
   a.A = (const bf16*)A; a.W = (const bf16*)W; a.C = (bf16*)C;
   a.A2 = (const bf16*)A2; a.W2 = (const bf16*)W2;
-  a.bias = nullptr; a.residual = nullptr;
+  a.bias = nullptr; a.residual = (const bf16*)residual;
   a.M = M; a.N = N; a.K = K; a.K2 = 64;
-  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = 0; a.lda2 = lda2; a.ldw2 = ldw2;
-  a.act = VLB_ACT_NONE; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
+  a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
   a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;

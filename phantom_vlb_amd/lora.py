@@ -26,6 +26,7 @@ from .geometry import Geometry
 
 BF16 = torch.bfloat16
 PAD = 64  # adapter rank columns padded to one GEMM K-tile
+FUSE_SWIGLU_BWD = True      # SwiGLU backward in the epilogue of the down projection's dgrad GEMM (A/B switch)
 
 
 def _stream():
@@ -250,8 +251,9 @@ class LoraState:
         return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
 
     # ------------------------------------------------------------------ backward
-    def _group_backward(self, li, gname, dy, x_in, t, seeds, W_t, need_dx):
-        """dy: grad of the group's (concatenated) output; x_in: the group's input; returns d x_in."""
+    def _group_backward(self, li, gname, dy, x_in, t, seeds, W_t, need_dx, swiglu_gu=None):
+        """dy: grad of the group's (concatenated) output; x_in: the group's input; returns d x_in - or, with
+        ``swiglu_gu`` (the saved [gate | up] activations x_in = silu(gate)*up came from), d [gate | up]."""
         lay = self.layers[li][gname]
         ws = self._workspace(dy.shape[0])
         u = ws["u"]
@@ -270,14 +272,17 @@ class LoraState:
         if not need_dx:
             return None
         if self.p == 0.0:
-            return ops.gemm(dy, W_t, a2=u, w2=lay["At"])
-        if lay["R"] == 16 and ops.gemm_masked_pair_ok(dy.shape[0], W_t.shape[0], dy.shape[1]):
+            dx = ops.gemm(dy, W_t, a2=u, w2=lay["At"])
+        elif lay["R"] == 16 and ops.gemm_masked_pair_ok(dy.shape[0], W_t.shape[0], dy.shape[1]):
             # single-projection groups (o, down): the dropout mask is applied to the u.A accumulators inside the
-            # dgrad GEMM - no read-modify-write pass over dx
-            return ops.gemm_masked_pair(dy, W_t, u, lay["At"], self.p, seeds[0])
-        dx = ops.gemm(dy, W_t)
-        lora_dx_masked(u, lay["At"], dx, lay["R"], self.p, seeds)
-        return dx
+            # dgrad GEMM - no read-modify-write pass over dx; for `down` the SwiGLU backward rides in its epilogue
+            if swiglu_gu is not None and FUSE_SWIGLU_BWD:
+                return ops.gemm_masked_pair_swiglu_bwd(dy, W_t, swiglu_gu, u, lay["At"], self.p, seeds[0])
+            dx = ops.gemm_masked_pair(dy, W_t, u, lay["At"], self.p, seeds[0])
+        else:
+            dx = ops.gemm(dy, W_t)
+            lora_dx_masked(u, lay["At"], dx, lay["R"], self.p, seeds)
+        return dx if swiglu_gu is None else ops.swiglu_bwd(swiglu_gu, dx)
 
     def backward(self, backbone, dhidden):
         """dhidden: d loss / d (post-final-norm hidden) bf16 [B*S, dim].  Fills self.grads."""
@@ -292,8 +297,7 @@ class LoraState:
         for li in range(g.layers - 1, -1, -1):
             lw, sv = backbone.layer_weights(li, transposed=True, direction=-1), self.saved[li]
             sd = sv["seeds"]
-            d_hh = self._group_backward(li, "down", dx, sv["hh"], sv["t_d"], sd[6:7], lw["wdown_t"], True)
-            d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
+            d_gu = self._group_backward(li, "down", dx, sv["hh"], sv["t_d"], sd[6:7], lw["wdown_t"], True, swiglu_gu=sv["gu"])
             d_h2 = self._group_backward(li, "gu", d_gu, sv["h2"], sv["t_gu"], sd[4:6], lw["wgu_t"], True)
             dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
             d_a = self._group_backward(li, "o", dx2, sv["a"], sv["t_o"], sd[3:4], lw["wo_t"], True)

@@ -122,6 +122,23 @@ def gemm_masked_pair(a, w, a2, w2, p, seed, out=None):
     return out
 
 
+def gemm_masked_pair_swiglu_bwd(dy, w_t, gu, a2, w2, p, seed, out=None):
+    """d[gate | up] of the MLP from dy (grad of the down projection's output): the LoRA-through-dropout dgrad GEMM
+    with the SwiGLU backward in its epilogue (d_h never hits memory).  gu: saved [M, 2*ff] activations."""
+    _dev(dy)
+    M, K = dy.shape
+    ff = w_t.shape[0]
+    assert w_t.shape[1] == K and gu.shape == (M, 2 * ff) and a2.shape[0] == M and w2.shape[0] == ff
+    if out is None:
+        out = torch.empty(M, 2 * ff, dtype=BF16, device=dy.device)
+    ws = _gemm_workspace(dy.device) if K + 64 >= 4096 and M * ff > 256 * 192 * 256 else None
+    check(lib.vlb_gemm_masked_pair_swiglu_bwd(dy.data_ptr(), dy.stride(0), w_t.data_ptr(), w_t.stride(0), gu.data_ptr(), gu.stride(0),
+                                              out.data_ptr(), out.stride(0), M, ff, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(),
+                                              w2.stride(0), float(p), int(seed) & 0xFFFFFFFF, _p(ws),
+                                              ws.numel() if ws is not None else 0, _stream()), "vlb_gemm_masked_pair_swiglu_bwd")
+    return out
+
+
 def interleave_gate_up(w_gate, w_up):
     """[gate; up] -> 16-row blocks [gate_0 | up_0 | gate_1 | up_1 | ...] for ACT_SWIGLU_PAIR."""
     ff, k = w_gate.shape

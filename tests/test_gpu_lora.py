@@ -305,3 +305,33 @@ def test_gemm_masked_pair_equals_gemm_plus_lora_dx(dev, M, N, K):
     assert rel_err(two, ref) < 1.2e-2            # the two-kernel path rounds to bf16 twice
     kept_frac = float(keep.float().mean())
     assert abs(kept_frac - 0.9) < 0.01
+
+
+@pytest.mark.parametrize("M,ff,K", [(700, 512, 256), (5861, 14336, 4096), (4500, 4096, 256), (2573, 6144, 4096)])
+def test_gemm_masked_pair_swiglu_bwd_matches_two_kernels(dev, M, ff, K):
+    """Down-projection dgrad with the SwiGLU backward in its epilogue == masked-pair GEMM followed by vlb_swiglu_bwd
+    (which rounds d_h to bf16 in between), and == the fp32 formula."""
+    from phantom_vlb_amd import ops
+    from phantom_vlb_amd.lora import PAD
+    g = torch.Generator().manual_seed(M + ff)
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).to(dev)
+    W = (torch.randn(ff, K, generator=g) * 0.05).to(BF).to(dev)
+    gu = torch.randn(M, 2 * ff, generator=g).to(BF).to(dev)
+    u = torch.zeros(M, PAD, dtype=BF)
+    u[:, :16] = (torch.randn(M, 16, generator=g) * 0.5).to(BF)
+    At = torch.zeros(ff, PAD, dtype=BF)
+    At[:, :16] = (torch.randn(ff, 16, generator=g) * 0.2).to(BF)
+    u, At = u.to(dev), At.to(dev)
+    seed, p = 0xBEEF1234, 0.1
+    fused = ops.gemm_masked_pair_swiglu_bwd(dy, W, gu, u, At, p, seed)
+    d_h = ops.gemm_masked_pair(dy, W, u, At, p, seed)
+    two = ops.swiglu_bwd(gu, d_h)
+    assert rel_err(fused, two.float()) < 6e-3
+    keep = keep_mask(seed, M, ff, p).to(dev)
+    dh = dy.float() @ W.float().t() + (u[:, :16].float() @ At[:, :16].float().t()) / (1 - p) * keep
+    gate, up = gu[:, :ff].float(), gu[:, ff:].float()
+    sg = torch.sigmoid(gate)
+    ref = torch.cat([dh * up * sg * (1 + gate * (1 - sg)), dh * gate * sg], dim=1)
+    assert rel_err(fused, ref) < 6e-3
+    again = ops.gemm_masked_pair_swiglu_bwd(dy, W, gu, u, At, p, seed)
+    assert torch.equal(fused, again)
