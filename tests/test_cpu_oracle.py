@@ -152,6 +152,38 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.vlb_head_partial_rows(2048) == 64
 
 
+def test_gemm_plan_host_arithmetic():
+    """vlb_gemm_plan (pure host code): how long-K GEMMs are cut into waves of tiles on the 256-CU chip - tile rows,
+    what happens to the partial last wave, K splits.  Pins the shapes DESIGN.md quotes."""
+    from phantom_vlb_amd import _lib
+    plan = _lib.lib.vlb_gemm_plan
+    assert _lib.lib.vlb_gemm_workspace_bytes() == 256 * 256 * 256 * 4
+    assert plan(5861, 28672, 4096, 64, 1) == 256208          # LoRA gate/up: 10 waves + 16 tiles x 8 K splits
+    assert plan(5861, 28672, 4096, 64, 0) == 256101          # without a workspace: re-cut 256x128 halves
+    assert plan(5861, 4096, 4096, 64, 1) == 192001           # o-proj: 31 x 16 tiles of 192 rows = two fuller waves
+    assert plan(9447, 4096, 14336, 0, 1) == 256203           # frozen down: 2 waves + 80 tiles x 3
+    assert plan(9447, 6144, 4096, 0, 1) == 256101            # 120 leftover tiles: two splits would cost more than halves
+    assert plan(5861, 14336, 4096, 64, 3) == 192001          # masked-pair rules: no split-K at 256 rows
+    assert plan(5861, 14336, 4096, 64, 1) == 256208
+    assert plan(10240, 6144, 4096, 0, 1) == 256001           # 960 tiles: whole waves only... 3.75 -> last wave kept whole
+    assert plan(4096, 4096, 1024, 0, 1) == 0                 # short K: the 8-wave kernel, no plan
+    for M in range(300, 12000, 517):                         # every plan is self-consistent
+        for N, K in ((4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336)):
+            for ws in (0, 1, 3):
+                p = plan(M, N, K, 64, ws)
+                rows, mode, sp = p // 1000, p // 100 % 10, p % 100
+                tiles = -(-M // rows) * (N // 256)
+                assert rows in (192, 256) and mode in (0, 1, 2)
+                if mode == 2:
+                    rem = tiles % 256
+                    assert ws and 2 <= sp <= 8 and 0 < rem and sp * rem <= 256 and (K + 64) // 64 // sp >= 8
+                    assert not (ws == 3 and rows == 256)
+                else:
+                    assert sp == 1
+                if mode:
+                    assert tiles > 256 and tiles % 256
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is the checker: nothing under phantom_vlb_amd/ (or train.py / src/) may reference it."""
     bad = []
