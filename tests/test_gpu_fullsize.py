@@ -43,6 +43,37 @@ def test_head_full_size_vs_oracle(dev):
     assert (dh.view(B, S, E)[wm.to(dev) == 0] == 0).all()
 
 
+def test_head_whole_cortex_size_vs_oracle(dev):
+    """The largest head BASELINE.json names (configs[4]: 65,536 targets; W is 537 MB in bf16): prediction, loss and
+    every gradient vs oracle autograd at B=2."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.head import HEAD_PARAMS, BrainHead
+    B, S, E, V = 2, 2048, 4096, 65536
+    g = O.Geometry(dim=E, num_target=V)
+    gen = torch.Generator().manual_seed(11)
+    p = O.round_bf16({n: t for n, t in O.init_params(O.geometry_mini(dim=E, num_target=V), seed=5).items() if n in HEAD_PARAMS})
+    hidden = (torch.randn(B, S, E, generator=gen) * 1.5).to(BF)
+    batch = O.synthetic_batch(O.geometry_7b(), B, seed=7)
+    wm = O.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], 866, 2048).to(BF).float()
+    y = torch.randn(B, V, generator=gen)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    hr = hidden.float().requires_grad_(True)
+    pred_ref, l2_ref, _ = O.brain_head(pr, hr, wm, g)
+    loss_ref = F.mse_loss(pred_ref, y) + l2_ref
+    loss_ref.backward()
+    head = BrainHead(E, V, g.l2_lambda, g.ln_eps, dev, sd=p)
+    pred, terms = head.forward(hidden.to(dev).view(B * S, E), wm.to(dev), y.to(dev))
+    assert abs(float(terms[2]) - float(loss_ref)) / float(loss_ref) < 1e-3
+    assert abs(float(terms[1]) - float(l2_ref)) / float(l2_ref) < 1e-3
+    assert rel_err(pred, pred_ref) < 8e-3
+    dh = head.backward(need_dhidden=True)
+    for n in HEAD_PARAMS:
+        assert rel_err(head.grads[n], pr[n].grad) < 1.5e-2, n
+    assert rel_err(dh.view(B, S, E), hr.grad) < 2e-2
+    del head
+    torch.cuda.empty_cache()
+
+
 def test_decoder_layer_full_size_vs_oracle(dev):
     """One Mistral-7B-sized decoder layer (+ final norm) on one 2048-token clip with 150 padded positions."""
     import dataclasses
