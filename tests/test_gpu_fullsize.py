@@ -114,6 +114,35 @@ def test_decoder_layer_full_size_vs_oracle(dev):
     assert torch.isfinite(got).all()
 
 
+def test_vision_tower_and_connector_full_size_vs_oracle(dev):
+    """One 12-frame clip through the ViT-L/14-336-wide tower (2 of its 23 layers: 577 tokens, 16 heads of 64,
+    patch-embed K=588) and the FULL STC connector (2 x 4 RegStage blocks at 4096 channels, Conv3d 12x24x24 ->
+    7x13x13, MLP readout) against the fp32 oracle: the frozen vision path at BASELINE's real widths."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.backbone import Backbone, Weights
+    from phantom_vlb_amd.geometry import geometry_7b
+    go = dataclasses.replace(O.geometry_7b(), layers=1, vit_layers=3)
+    p = O.round_bf16(O.init_params(go, seed=8))
+    g = dataclasses.replace(geometry_7b(), layers=1, vit_layers=3)
+    assert g.vit_layers_run == 2 and g.vis_tokens == 1183
+    gen = torch.Generator().manual_seed(9)
+    pix = torch.randn(g.num_frames, 3, g.image_size, g.image_size, generator=gen)
+    with torch.no_grad():
+        feats_ref = O.clip_tower(p, pix, go)
+        vid_ref = O.stc_connector(p, feats_ref.view(1, g.num_frames, g.grid * g.grid, g.vit_dim), go)
+    bb = Backbone(g, Weights(g, p, dev))
+    feats = bb.vision_tower(pix.to(dev))
+    assert feats.shape == (g.num_frames * g.grid * g.grid, g.vit_dim)
+    assert rel_err(feats.view(g.num_frames, -1, g.vit_dim), feats_ref) < 2e-2
+    vid = bb.connector(feats, 1)
+    assert vid.shape == (g.vis_tokens, g.dim)
+    assert rel_err(vid.view(1, g.vis_tokens, g.dim), vid_ref) < 5e-2
+    assert torch.isfinite(vid.float()).all()
+    del bb
+    torch.cuda.empty_cache()
+
+
 def test_gemm_full_size_sampled_rows(dev):
     """gate/up and down projections at M = 10240: 512 sampled rows against fp32 torch on the GPU."""
     from phantom_vlb_amd import ops
