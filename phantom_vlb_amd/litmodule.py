@@ -180,8 +180,8 @@ class VLBLitModule(_Base):
         vis = self._vision_tensor(x_video)
         ids = x_lang.to(self.device, torch.int64).contiguous()
         B = ids.shape[0]
-        if self.lora is not None and self.training:
-            hidden, key_mask = self.lora.forward(self.backbone, vis, ids, layout)
+        if self.lora is not None:        # eval mode keeps the adapters (peft eval: dropout off), like the reference's validation
+            hidden, key_mask = self.lora.forward(self.backbone, vis, ids, layout, train=self.training)
         else:
             hidden, key_mask = self.backbone.forward(vis, ids, layout=layout)
         if y is None:

@@ -207,27 +207,30 @@ class LoraState:
             self._t_bufs = torch.zeros(len(self.layers), len(GROUPS), M, PAD, dtype=BF16, device=self.dev)
         return self._t_bufs[li, gi, :M]
 
-    def _adapted(self, x, W, blk, seeds, residual=None, slot=None):
+    def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None):
         t = self._t_buffer(*slot, x.shape[0]) if slot is not None else torch.zeros(x.shape[0], PAD, dtype=BF16, device=self.dev)
-        lora_down(x, blk["A"], blk["R"], self.scale, self.p, seeds, t)
+        lora_down(x, blk["A"], blk["R"], self.scale, self.p if p is None else p, seeds, t)
         return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
 
-    def forward(self, backbone, vision_f32, ids, layout=None):
-        """Training forward of the whole backbone; decoder activations are kept for backward.
+    def forward(self, backbone, vision_f32, ids, layout=None, train=True):
+        """Forward of the whole backbone with the adapters.  train=True: dropout on, decoder activations kept for
+        backward.  train=False (validation; peft in eval mode): same adapters, no dropout, nothing kept.
         ``layout``: packed RowLayout (rows without the clips' padded tails) or None for dense [B,S]."""
         g = self.g
         B = vision_f32.shape[0]
         pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
         vid = backbone.connector(backbone.vision_tower(pix), B)          # frozen: no activations kept
         x, key_mask = backbone.splice(ids, vid, layout)
-        return self.decoder_forward(backbone, x, key_mask, B, layout)
+        return self.decoder_forward(backbone, x, key_mask, B, layout, train=train)
 
-    def decoder_forward(self, backbone, x, key_mask, B, layout=None):
+    def decoder_forward(self, backbone, x, key_mask, B, layout=None, train=True):
         """The adapted decoder on spliced embeddings x [rows, dim] (the part of forward() that keeps activations)."""
         g, w = self.g, self.w
         S = g.max_len
         pos = None if layout is None else layout.pos
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        if not train:
+            return self._decoder_eval(backbone, x, key_mask, B, layout)
         self.saved = []
         self.step += 1
         for li, lay in enumerate(self.layers):
@@ -248,6 +251,25 @@ class LoraState:
                                    t_gu=t_gu, t_d=t_d, seeds=sd))
             x = x3
         self.x_last, self.key_mask, self.B, self.layout = x, key_mask, B, layout
+        return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
+
+    def _decoder_eval(self, backbone, x, key_mask, B, layout):
+        """Adapted decoder without dropout and without saved activations (validation / inference)."""
+        g, w = self.g, self.w
+        S = g.max_len
+        pos = None if layout is None else layout.pos
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        for li, lay in enumerate(self.layers):
+            lw = backbone.layer_weights(li)
+            h = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
+            qkv, _ = self._adapted(h, lw["wqkv"], lay["qkv"], None, slot=(li, 0), p=0.0)
+            ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
+            a = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads, g.head_dim,
+                                  True, g.head_dim ** -0.5, key_mask=key_mask, layout=layout)
+            x, _ = self._adapted(a, lw["wo"], lay["o"], None, residual=x, slot=(li, 1), p=0.0)
+            h = ops.rmsnorm(x, lw["post_norm"], g.rms_eps)
+            gu, _ = self._adapted(h, lw["wgu"], lay["gu"], None, slot=(li, 2), p=0.0)
+            x, _ = self._adapted(ops.swiglu(gu), lw["wdown"], lay["down"], None, residual=x, slot=(li, 3), p=0.0)
         return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
 
     # ------------------------------------------------------------------ backward

@@ -365,3 +365,44 @@ def test_lora_decoder_layer_full_size_fwd_bwd_vs_oracle(dev):
         worst = max(worst, e)
         assert e < 4e-2, (n, e)
     assert len(names) == 14 and worst > 0
+
+
+def test_7b_lora_step_init_properties(dev):
+    """Whole 7B LoRA step (32 layers, B=1) at initialisation, where peft's B = 0 gives size-independent facts:
+    every lora_A gradient is EXACTLY zero (dA = (s dY.B)^T x and B = 0), every lora_B gradient is finite and non-zero,
+    the validation loss (adapters on, dropout off) equals the training loss, and both equal the frozen-backbone loss of
+    the same weights to bf16 rounding (the adapters add exactly 0 to every GEMM)."""
+    import warnings
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.synthetic import synthetic_batch
+    kw = dict(model_path="none", dropout_rate=0.0, num_target=2048, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999], eps=1e-8,
+              weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="7b")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VLBLitModule(VLBLitModuleConfig(freeze_backbone=False, use_lora=True, lora_r=16, lora_alpha=32, lora_dropout=0.1, **kw))
+        m.configure_model()
+    m.configure_optimizers()
+    batch = synthetic_batch(m.geometry, 1, seed=5, device=m.device)
+    batch["language"], batch["padvals"] = batch["language"].cpu(), batch["padvals"].cpu()
+    loss = float(m.training_step(batch))
+    n_a = n_b = 0
+    for n, p in m.trainable_named_parameters():
+        if "lora_A" in n:
+            assert p.grad.count_nonzero().item() == 0, n
+            n_a += 1
+        elif "lora_B" in n:
+            assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+            n_b += 1
+    assert n_a == n_b == 32 * 7
+    # validation (eval mode: adapters on, dropout off) at B = 0 runs the same GEMMs with an exactly-zero adapter term
+    val = float(m.validation_step(batch)["loss"])
+    assert abs(val - loss) <= 1e-5 * abs(loss), (val, loss)
+    # ... and the bare frozen backbone (fused SwiGLU epilogue instead of the saved gate/up) agrees to bf16 rounding
+    lora, m.lora = m.lora, None
+    try:
+        frozen = float(m.validation_step(batch)["loss"])
+    finally:
+        m.lora = lora
+    assert abs(frozen - loss) <= 3e-3 * abs(loss), (frozen, loss)
+    del m
+    torch.cuda.empty_cache()

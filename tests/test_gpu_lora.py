@@ -228,6 +228,34 @@ def test_mini_lora_training_step_vs_golden(dev):
     assert torch.equal(m.lora.layers[0]["qkv"]["At"][:, :48], m.lora.layers[0]["qkv"]["A"].t())
 
 
+def test_validation_step_applies_the_adapters(dev):
+    """validation_step (reference :309-342 runs the peft model in eval mode: adapters on, dropout off).  With trained
+    (B != 0) adapters and LoRA dropout configured, the validation loss is the golden adapted loss, not the loss of the
+    bare frozen backbone, and it does not depend on the dropout seed."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.lora import LoraState
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=1234, lora=True, lora_b_std=0.02))
+    batch = O.synthetic_batch(g, 4, seed=1234)
+    gold = np.load(os.path.join(GOLD, "mini_lora.npz"))
+    m = VLBLitModule(_lora_cfg())
+    m.configure_model(state_dict=p, head_state=p)
+    m.lora = LoraState(m.geometry, m.backbone.w, 16, 32, 0.1, m.device, sd=p)      # dropout configured: must be off in eval
+    m.configure_optimizers()
+    out = m.validation_step(batch)
+    assert abs(float(out["loss"]) - float(gold["loss"])) / float(gold["loss"]) < 1e-3
+    assert rel_err(out["brain_preds"], torch.from_numpy(gold["pred"])) < 3e-2
+    again = m.validation_step(batch)
+    assert torch.equal(out["brain_preds"], again["brain_preds"])
+    # the bare backbone (adapters ignored) gives a measurably different prediction: this is what eval mode must NOT return
+    lora, m.lora = m.lora, None
+    bare = m.validation_step(batch)
+    m.lora = lora
+    assert rel_err(bare["brain_preds"], torch.from_numpy(gold["pred"])) > 2 * rel_err(out["brain_preds"], torch.from_numpy(gold["pred"]))
+    assert m.training                                                                # mode restored
+
+
 def test_mini_lora_dropout_matches_oracle(dev):
     """LoRA dropout 0.1: the oracle is fed the SAME counter-based masks (restated in numpy)."""
     import vlb_oracle as O
