@@ -74,7 +74,7 @@ class RidgeRegressionLayer:
 class LogValAccuracyCallback(_Callback):
     """Per-target Pearson r over the validation set (src/utils.py:85-110), streamed: five running sums
     per target on the device instead of concatenating every prediction, and ONE tensor of per-target
-    correlations instead of num_target separate log() calls (kept available as `correlations`)."""
+    correlations (kept available as `correlations`) copied to the host once before the per-ROI log() calls."""
 
     def on_validation_epoch_start(self, trainer, pl_module):
         self.n = 0
@@ -95,6 +95,10 @@ class LogValAccuracyCallback(_Callback):
         cov = spy - sp * sy / n
         var = (spp - sp * sp / n) * (syy - sy * sy / n)
         self.correlations = (cov / var.clamp_min(1e-30).sqrt()).float()
-        for i in range(min(pl_module.config.num_target, 16)):          # a few per-ROI scalars for the log
-            pl_module.log(f"val_corr_ROI_{i:0{6}}", self.correlations[i])
+        # one scalar per target, like the reference (:105-110) - from ONE device->host copy instead of num_target syncs;
+        # max_roi_logs caps the count for whole-cortex heads (65,536 log() calls per validation epoch otherwise)
+        host = self.correlations.cpu().tolist()
+        limit = getattr(self, "max_roi_logs", None)
+        for i in range(pl_module.config.num_target if limit is None else min(pl_module.config.num_target, limit)):
+            pl_module.log(f"val_corr_ROI_{i:0{6}}", host[i])
         pl_module.log("val_corr_avg", self.correlations.mean())

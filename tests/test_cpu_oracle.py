@@ -255,3 +255,6 @@ def test_streaming_pearson_callback_matches_definition():
     cb.on_validation_epoch_end(None, m)
     ref = torch.stack([torch.corrcoef(torch.stack([preds[:, j], vals[:, j]]))[0, 1] for j in range(5)])
     assert torch.allclose(cb.correlations, ref, atol=1e-5) and abs(m.logged["val_corr_avg"] - float(ref.mean())) < 1e-5
+    # one scalar per target under the reference's key format (src/utils.py:108-109)
+    assert [k for k in m.logged if k.startswith("val_corr_ROI_")] == [f"val_corr_ROI_{i:06d}" for i in range(5)]
+    assert abs(m.logged["val_corr_ROI_000000"] - 1.0) < 1e-5
