@@ -121,16 +121,16 @@ class Trainer:
 
     def validate(self, model, loader):
         self._cb("on_validation_epoch_start", model)
-        tot, n = 0.0, 0
+        tot, n = None, 0                     # summed on the device: one host sync per validation epoch, not per batch
         for bi, batch in enumerate(loader):
             if self.limit_val_batches is not None and bi >= self.limit_val_batches:
                 break
             out = model.validation_step(batch)
             self._cb("on_validation_batch_end", model, out, batch, bi)
-            tot += float(out["loss"])
+            tot = out["loss"].detach().double() if tot is None else tot + out["loss"].detach().double()
             n += 1
         self._cb("on_validation_epoch_end", model)
-        metrics = {"val/brain_loss": tot / max(n, 1)}
+        metrics = {"val/brain_loss": (float(tot) if tot is not None else 0.0) / max(n, 1)}
         metrics.update({k: float(v) for k, v in getattr(model, "logged", {}).items() if k.startswith("val_corr_avg")})
         for c in self.callbacks:
             if hasattr(c, "on_validation_end") and isinstance(c, TrainableCheckpoint):
@@ -158,6 +158,7 @@ class Trainer:
         if torch.cuda.is_available():        # overlap the next batch's host->device copy with the current step
             from .datamodule import DevicePrefetcher
             train_loader = DevicePrefetcher(train_loader, model.device)
+            val_loader = DevicePrefetcher(val_loader, model.device)
         n_batches = len(train_loader)
         val_every = max(1, int(n_batches * self.val_check_interval)) if self.val_check_interval <= 1 else int(self.val_check_interval)
         t0 = time.time()
