@@ -77,7 +77,9 @@ GROUPS = (
 class LoraState:
     def __init__(self, g: Geometry, weights, r: int, alpha: int, dropout: float, device, seed: int = 1234,
                  sd: dict | None = None):
-        assert r == 16, "kernels are specialised for r = 16 (the reference's lora_r)"
+        if r != 16:
+            raise NotImplementedError(f"lora_r={r}: the adapter kernels are specialised for r = 16, the reference's setting "
+                                      "(config/experiment/VLB_vllama2_friends_lora.yaml:27)")
         self.g, self.w, self.r, self.dev = g, weights, r, device
         self.scale = alpha / r
         self.p = float(dropout)
