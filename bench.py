@@ -2,7 +2,9 @@
 
   python bench.py --gpus 1 --steps 8 --warmup 2            # configs[2]: 7B + LoRA r=16 + 2k head, B=3/GPU (the metric's config)
   python bench.py --workload frozen                        # configs[1]: 7B frozen backbone + 2k head, B=5/GPU
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N                                 # launches N ranks itself (one per GPU, RCCL), prints rank 0's line
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     # what the driver does; same result
+  python bench.py --gpus N --shard-frozen                  # fsdp.yaml-equivalent: frozen decoder weights sharded 1/N as well
 
 A "step" = forward through CLIP tower + STC connector + splice + 32 Mistral layers (+LoRA) + brain head,
 backward through head and decoder (LoRA A/B gradients), global-norm clip, AdamW, cosine LR - all on
@@ -50,60 +52,123 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(g7, num_target):
-    """Oracle (oracle/vlb_oracle.py, kind 'port') on the host cores: ONE clip through 2 ViT layers,
-    the full connector, 2 decoder layers and the full head in fp32; ViT/decoder times are scaled to
-    23/32 layers.  Returns (clips_per_s, cores, sample description)."""
+def cpu_baseline(num_target, lora):
+    """Oracle (oracle/vlb_oracle.py, kind 'port') on the host cores, bounded sample: ONE clip through 2 ViT layers,
+    the full connector, 2 decoder layers and the full head in fp32 - forward, and for the LoRA workload ALSO the
+    backward pass (torch autograd through head + adapted decoder layers, exactly the gradients the step needs);
+    ViT / decoder times are scaled to 23 / 32 layers.  Plus configs[0] exactly: one full training
+    step (forward, backward, clip, AdamW) of the mini model on 4 clips.  Returns the cpu_baseline object."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vlb_oracle as O
     import dataclasses
     cores = torch.get_num_threads()
-    g = dataclasses.replace(O.geometry_7b(num_target=num_target), vit_layers=3, layers=2)
-    p = O.init_params(g, seed=1)
+    kw = dict(lora_r=16, lora_alpha=32) if lora else {}
+    g = dataclasses.replace(O.geometry_7b(num_target=num_target, **kw), vit_layers=3, layers=2)
+    p = O.init_params(g, seed=1, lora=lora, lora_b_std=0.02) if lora else O.init_params(g, seed=1)
+    train = O.trainable_names(p, freeze_backbone=not lora, use_lora=lora)
+    for n in train:
+        p[n].requires_grad_(True)
     batch = O.synthetic_batch(g, 1, seed=1)
-    with torch.no_grad():
-        t0 = time.perf_counter()
+    t0 = time.perf_counter()
+    with torch.no_grad():                                  # frozen in every measured configuration: forward only
         pix = batch["vision"].reshape(g.num_frames, 3, g.image_size, g.image_size)
         vit = O.clip_tower(p, pix, g).view(1, g.num_frames, -1, g.vit_dim)
         t1 = time.perf_counter()
         vid = O.stc_connector(p, vit, g)
         t2 = time.perf_counter()
         emb, km = O.splice_multimodal(p["model.embed_tokens.weight"], batch["language"].long(), vid)
+    with torch.set_grad_enabled(lora):
         hid = O.mistral_decoder(p, emb, km, g)
-        t3 = time.perf_counter()
-        wm = O.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], g.lang_len, g.max_len, g.ds_grid ** 2)
-        pred, l2, _ = O.brain_head(p, hid, wm, g)
-        t4 = time.perf_counter()
+    t3 = time.perf_counter()
+    wm = O.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], g.lang_len, g.max_len, g.ds_grid ** 2)
+    hid_head = hid if lora else hid.detach()
+    pred, l2, _ = O.brain_head(p, hid_head, wm, g)
+    loss = torch.nn.functional.mse_loss(pred, batch["timeseries"]) + l2
+    t4 = time.perf_counter()
+    if lora:                                               # decoder backward dominates; head backward rides along
+        loss.backward()
+        t5 = time.perf_counter()
+        t_bwd_dec, t_bwd_head = t5 - t4, 0.0
+    else:
+        loss.backward()                                    # head only
+        t5 = time.perf_counter()
+        t_bwd_dec, t_bwd_head = 0.0, t5 - t4
     t_vit, t_conn, t_dec, t_head = t1 - t0, t2 - t1, t3 - t2, t4 - t3
-    total = t_vit * (23 / 2) + t_conn + t_dec * (32 / 2) + t_head
-    sample = (f"1 clip fp32 forward: 2 ViT layers {t_vit:.1f}s x23/2 + connector {t_conn:.1f}s + 2 decoder layers "
-              f"{t_dec:.1f}s x32/2 + head {t_head:.2f}s = {total:.0f}s/clip (extrapolated, forward only)")
-    return 1.0 / total, cores, sample
+    total = t_vit * (23 / 2) + t_conn + (t_dec + t_bwd_dec) * (32 / 2) + t_head + t_bwd_head
+    sample = (f"1 clip fp32, oracle on the host: 2 ViT layers fwd {t_vit:.1f}s x23/2 + connector fwd {t_conn:.1f}s + 2 decoder layers "
+              f"fwd {t_dec:.1f}s" + (f" + bwd (autograd, LoRA+head grads) {t_bwd_dec:.1f}s" if lora else "")
+              + f" x32/2 + head fwd {t_head:.2f}s" + (f" + bwd {t_bwd_head:.2f}s" if not lora else "")
+              + f" = {total:.0f}s/clip (layers extrapolated; optimiser update not included)")
+    # ---- configs[0], exact: mini model, 4 clips, one full training step on the CPU
+    gm = O.geometry_mini(**kw)
+    pm = O.round_bf16(O.init_params(gm, seed=1234, lora=lora, lora_b_std=0.02) if lora else O.init_params(gm, seed=1234))
+    bm = O.synthetic_batch(gm, 4, seed=1234)
+    names = O.trainable_names(pm, freeze_backbone=not lora, use_lora=lora)
+
+    def mini_step():
+        q = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in pm.items()}
+        l, _ = O.training_loss(q, bm, gm)
+        l.backward()
+        grads, _ = O.clip_grad_norm({k: q[k].grad for k in names}, 1.0)
+        for k in names:
+            O.adamw_step(q[k].detach(), grads[k], torch.zeros_like(grads[k]), torch.zeros_like(grads[k]), 1, 1e-4)
+    mini_step()
+    tm = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        mini_step()
+    tm = (time.perf_counter() - tm) / reps
+    return {"value": round(1.0 / total, 6), "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample,
+            "mini": {"value": round(4 / tm, 3), "unit": "clips/s", "workload": "configs[0]: mini 2-layer model + 128-voxel head, 4 clips, "
+                     "one full training step (fwd + bwd + clip + AdamW), exact (no extrapolation)", "ms_per_step": round(tm * 1e3, 2)}}
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) BEFORE this process touches the GPU,
+    relay their output (rank 0 prints the JSON line) and return their exit status.  Never falls back to fewer ranks:
+    with fewer than N visible devices this fails, unless VLB_DIST_BACKEND=gloo asks for a time-shared rehearsal."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()                  # does not initialise the GPU
+    rehearsal = os.environ.get("VLB_DIST_BACKEND", "nccl") != "nccl"
+    if ndev < a.gpus and not rehearsal:
+        print(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     ndev = torch.cuda.device_count()
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)      # wraps only when rehearsing N ranks on fewer GPUs
+    backend = os.environ.get("VLB_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        print(f"bench.py: {world} RCCL ranks need {world} GPUs, {ndev} visible", file=sys.stderr)
+        sys.exit(2)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)      # wraps only in a gloo rehearsal of N ranks on fewer GPUs
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # VLB_FORCE_DIST=1 runs the multi-process code path (RCCL init, flat-bucket all-reduce, barriers)
-    # even at world size 1 - used to rehearse `--gpus N` on a one-GPU box.
-    use_dist = world > 1 or os.environ.get("VLB_FORCE_DIST") == "1"
+    # VLB_FORCE_DIST=1 runs the multi-process code path (RCCL init, reduce-scatter / all-gather of the sharded
+    # optimiser state, barriers) even at world size 1 - used to rehearse `--gpus N` on a one-GPU box.
+    force = os.environ.get("VLB_FORCE_DIST") == "1"
+    use_dist = world > 1 or force
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        backend = os.environ.get("VLB_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     from phantom_vlb_amd import ops
-    if os.environ.get("VLB_GEMM_VARIANT"):        # A/B of GEMM kernel selection on the real step (tuning hook)
-        import ctypes
-        from phantom_vlb_amd._lib import lib
-        lib.vlb_gemm_set_variant.argtypes, lib.vlb_gemm_set_variant.restype = [ctypes.c_int, ctypes.c_int], None
-        lib.vlb_gemm_set_variant(int(os.environ["VLB_GEMM_VARIANT"], 0), 0)
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
 
@@ -124,11 +189,12 @@ def main():
         m.backbone.enable_sharding()
     opt, sch = m.configure_optimizers()
     opt, sch = opt[0], sch[0]["scheduler"]
+    comm_name = "none"
     if use_dist:
         from phantom_vlb_amd.parallel import attach_data_parallel, sync_module_states
-        red = attach_data_parallel(m, opt)
-        red.force = True                      # all-reduce even at world size 1 (rehearsal)
+        state = attach_data_parallel(m, opt, force_collectives=force)
         sync_module_states(m)                 # rank 0's trainables everywhere + derived layouts rebuilt
+        comm_name = f"{type(state.comm).__name__}/{backend} world={torch.distributed.get_world_size()}"
     g = m.geometry
     batch = synthetic_batch(g, B, seed=1234 + rank, device=dev)
     # pixels / targets / weights are resident in HBM; the ids and padvals (20 KB) stay on the host, as a
@@ -178,7 +244,12 @@ def main():
                                     if not lora else "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16")
                        if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
-                       "num_target": cfg.num_target, "weights": "random-init", "parallelism": f"dp{world}" + ("+sharded-frozen-weights" if a.shard_frozen else ""),
+                       "num_target": cfg.num_target, "weights": "random-init",
+                       "parallelism": f"dp{world}: clips sharded over ranks; trainables' gradients reduce-scattered, fp32 master + Adam moments "
+                                      f"sharded 1/{world}, bf16 copies all-gathered; frozen weights "
+                                      + ("sharded 1/N per layer, all-gathered one layer ahead (fsdp.yaml FULL_SHARD equivalent)"
+                                         if a.shard_frozen else "replicated (--shard-frozen for the fsdp.yaml-equivalent layout)"),
+                       "comm": comm_name,
                        "loss": round(float(loss), 6),
                        "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "token_rows": {"computed": rows_run, "padded_layout": rows_dense,
@@ -196,11 +267,7 @@ def main():
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":
-            v, cores, sample = cpu_baseline(g, cfg.num_target)
-            if lora:      # the oracle sample is forward only; the LoRA step adds dgrad + attention/LoRA backward
-                v = v * TFLOP_PER_CLIP["frozen"] / TFLOP_PER_CLIP["lora"]
-                sample += f"; LoRA step scaled by algorithmic FLOPs {TFLOP_PER_CLIP['lora']}/{TFLOP_PER_CLIP['frozen']} (backward not timed)"
-            out["cpu_baseline"] = {"value": round(v, 6), "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
+            out["cpu_baseline"] = cpu_baseline(cfg.num_target, lora)
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()

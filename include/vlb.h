@@ -294,6 +294,11 @@ int vlb_adamw_step(float* master, void* param_bf16, const float* grad, float* m,
                    float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
                    float max_norm, void* stream);
 
+/* head dropout mask (litmodule :226,251 nn.Dropout(p) in training): out[i] = keep_i / (1-p), keep_i from a
+ * counter-based hash of (seed, i) with 16 random bits per element (same mixer as the LoRA masks).  The result is
+ * what vlb_head_fwd / vlb_head_bwd take as `keep_scale`. */
+int vlb_dropout_keep_scale(float* out, int64_t n, float p, uint32_t seed, void* stream);
+
 /* misc */
 int vlb_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);

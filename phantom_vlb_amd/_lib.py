@@ -64,6 +64,7 @@ SIGNATURES = {
     "vlb_sumsq_ws_floats": [],
     "vlb_grad_sumsq": [P, L, P, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
+    "vlb_dropout_keep_scale": [P, L, F, ctypes.c_uint32, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }

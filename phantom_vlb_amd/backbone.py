@@ -262,6 +262,34 @@ class Backbone:
             h = ops.swiglu(ops.gemm(h, lw["wgu"]))
         return ops.gemm(h, lw["wdown"], residual=x)
 
+    def named_modules(self):
+        """(upstream module name, leaf) for every ``nn.Linear`` of ``Videollama2MistralForCausalLM`` as the weights
+        here imply it - what ``find_all_linear_names`` (reference litmodule :36-55) walks.  Convolutions of the
+        connector / patch embedding are not linears upstream and are not listed; ``lm_head`` exists upstream
+        (its logits are never read by the loss, so no weight is held here) and is listed so that the caller's
+        explicit removal of it is exercised."""
+        from .litmodule import _LinearInfo
+        g = self.g
+        qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
+        for i in range(g.vit_layers):
+            p = f"{V_PRE}.encoder.layers.{i}"
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                yield f"{p}.self_attn.{n}", _LinearInfo(g.vit_dim, g.vit_dim)
+            yield f"{p}.mlp.fc1", _LinearInfo(g.vit_ff, g.vit_dim)
+            yield f"{p}.mlp.fc2", _LinearInfo(g.vit_dim, g.vit_ff)
+        for n in ("readout.0", "readout.2"):
+            yield f"{M_PRE}.{n}", _LinearInfo(g.dim, g.dim)
+        for i in range(g.layers):
+            p = f"model.layers.{i}"
+            yield f"{p}.self_attn.q_proj", _LinearInfo(qd, g.dim)
+            yield f"{p}.self_attn.k_proj", _LinearInfo(kd, g.dim)
+            yield f"{p}.self_attn.v_proj", _LinearInfo(kd, g.dim)
+            yield f"{p}.self_attn.o_proj", _LinearInfo(g.dim, qd)
+            yield f"{p}.mlp.gate_proj", _LinearInfo(g.ff, g.dim)
+            yield f"{p}.mlp.up_proj", _LinearInfo(g.ff, g.dim)
+            yield f"{p}.mlp.down_proj", _LinearInfo(g.dim, g.ff)
+        yield "lm_head", _LinearInfo(g.vocab, g.dim)
+
     def splice(self, ids, video_tokens, layout=None):
         g = self.g
         return ops.splice_embed(ids, self.w.embed, video_tokens, g.vis_tokens, VIDEO_TOKEN_ID, self.err_flag, layout)

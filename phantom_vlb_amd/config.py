@@ -13,9 +13,14 @@ import re
 
 import yaml
 
-_FALLBACK_TARGETS = {
+# Lightning `_target_`s of the reference's YAML are ALWAYS routed to the built-in runner, whether or not Lightning is
+# installed: VLBLitModule's backward is explicit (no autograd graph), which Lightning's fit loop cannot drive
+# (automatic optimisation calls loss.backward(); manual optimisation rejects `gradient_clip_val`).  INTEGRATION.md.
+ROUTED_TARGETS = {
     "lightning.pytorch.Trainer": "phantom_vlb_amd.trainer.Trainer",
     "lightning.pytorch.loggers.CSVLogger": "phantom_vlb_amd.trainer.CSVLogger",
+    "lightning.pytorch.callbacks.LearningRateMonitor": "phantom_vlb_amd.trainer.LearningRateMonitor",
+    "lightning.pytorch.callbacks.ModelCheckpoint": "phantom_vlb_amd.trainer.TrainableCheckpoint",
 }
 
 
@@ -111,10 +116,5 @@ def instantiate(node, **extra):
     kwargs = {k: instantiate(v) for k, v in node.items() if k != "_target_"}
     kwargs.update(extra)
     target = str(node["_target_"]).strip()
-    try:
-        cls = _locate(target)
-    except Exception:
-        if target not in _FALLBACK_TARGETS:
-            raise
-        cls = _locate(_FALLBACK_TARGETS[target])
+    cls = _locate(ROUTED_TARGETS.get(target, target))
     return cls(**kwargs)

@@ -728,6 +728,32 @@ extern "C" int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void*
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
+// Head dropout (litmodule :226,251): keep/(1-p) per element from a counter-based hash of (seed, index) - the
+// same lowbias32 mixer as the LoRA dropout masks (lora.hip), 16 random bits per element, so the mask is a pure
+// function of (seed, position): nothing to store, and a resumed run needs only the step counter behind the seed.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__global__ void dropout_keep_scale_kernel(float* __restrict__ out, int64_t n, uint32_t key, uint32_t thresh, float inv_keep) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= n) return;
+  const uint32_t h = mix32((uint32_t)(i >> 1) ^ key);
+  out[i] = (h & 0xffffu) >= thresh ? inv_keep : 0.f;
+  if (i + 1 < n) out[i + 1] = (h >> 16) >= thresh ? inv_keep : 0.f;
+}
+static inline uint32_t mix32_host(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+extern "C" int vlb_dropout_keep_scale(float* out, int64_t n, float p, uint32_t seed, void* stream) {
+  VLB_REQUIRE(out && n > 0 && n < ((int64_t)1 << 32) && p >= 0.f && p < 1.f, "dropout_keep_scale: bad args");
+  const uint32_t thresh = (uint32_t)(p * 65536.f + 0.5f);
+  hipLaunchKernelGGL(dropout_keep_scale_kernel, dim3(grid_for((n + 1) / 2, 256)), dim3(256), 0, as_stream(stream), out, n,
+                     mix32_host(seed), thresh, 1.f / (1.f - p));
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
 extern "C" int vlb_sumsq_ws_floats(void) { return kSumsqBlocks; }
 extern "C" int vlb_grad_sumsq(const float* g, int64_t n, float* sumsq, float* ws, void* stream) {
   VLB_REQUIRE(n > 0 && g && sumsq && ws, "grad_sumsq: bad args");

@@ -20,12 +20,13 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
 
-try:
-    from lightning.pytorch import LightningDataModule as _Base  # type: ignore
-except Exception:  # pragma: no cover
-    class _Base:
-        def __init__(self):
-            pass
+
+class _Base:
+    """Stand-in for ``lightning.pytorch.LightningDataModule``: the built-in Trainer only calls ``train_dataloader`` /
+    ``val_dataloader`` (see litmodule._Base for why the real Lightning classes are never subclassed)."""
+
+    def __init__(self):
+        pass
 
 MODS_T = ("timeseries", "vision", "language")
 MODS_N = ("padvals", "vis_weights", "lang_weights")
@@ -156,11 +157,13 @@ class VLBDataModule(_Base):
                           sampler=sampler, num_workers=self.config.num_workers, pin_memory=torch.cuda.is_available())
 
     def train_dataloader(self, rank: int = 0, world: int = 1):
-        sampler = None
-        if world > 1:       # the reference has no DistributedSampler: ranks draw disjoint, rank-strided clips
-            from torch.utils.data.distributed import DistributedSampler
-            sampler = DistributedSampler(self.datasets.train, num_replicas=world, rank=rank, shuffle=True,
-                                         seed=self.config.random_state, drop_last=True)
+        """reference :219-225 (shuffle=True).  The permutation is a function of (random_state, epoch) - set by
+        ``sampler.set_epoch`` - instead of the global torch RNG, so a run resumed from a checkpoint continues with
+        the same clip order; under data parallelism ranks draw disjoint, rank-strided clips of that permutation
+        (the reference has no DistributedSampler: it never ran multi-GPU in mainline)."""
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(self.datasets.train, num_replicas=world, rank=rank, shuffle=True,
+                                     seed=self.config.random_state, drop_last=world > 1)
         return self.x_dataloader(dataset=self.datasets.train, sampler=sampler)
 
     def val_dataloader(self):

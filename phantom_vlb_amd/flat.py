@@ -12,6 +12,10 @@ from __future__ import annotations
 import torch
 
 BF16 = torch.bfloat16
+# Segment ends (the head, every decoder layer) are padded to a multiple of 8 * lcm(1..8) elements, so any run of
+# whole segments splits evenly into 1/world shards of 16-byte-aligned tensors for every world size up to 8 (and
+# any other divisor of 840): the unit parallel.ShardedFlatState reduce-scatters and all-gathers.
+SEG_ALIGN = 8 * 840
 
 
 class FlatTrainables:
@@ -34,16 +38,21 @@ class FlatTrainables:
                     groups.append((li, gname, a_names, b_names))
                     for n in a_names + b_names:
                         entries.append((n, lora.master[n].numel(), tuple(lora.master[n].shape)))
-        offs, off = {}, 0
-        for n, k, shp in entries:
+        def seg_of(n):
+            return int(n.split(".")[2]) if n.startswith("model.layers.") else -1      # -1 = the head
+
+        offs, off, seg_start = {}, 0, 0
+        for i, (n, k, shp) in enumerate(entries):
             offs[n] = (off, k, shp)
             off += (k + 7) // 8 * 8              # keep every tensor 32-byte aligned (16 B in bf16)
+            if i + 1 == len(entries) or seg_of(entries[i + 1][0]) != seg_of(n):
+                off = (off + SEG_ALIGN - 1) // SEG_ALIGN * SEG_ALIGN
+                if seg_of(n) < 0:
+                    self.head_range = (seg_start, off)
+                else:
+                    self.layer_ranges.append((seg_start, off))
+                seg_start = off
         self.numel = off
-        if lora is not None:
-            for li in range(len(lora.layers)):
-                names = [n for n, _, _ in entries if n.startswith(f"model.layers.{li}.")]
-                first, last = offs[names[0]], offs[names[-1]]
-                self.layer_ranges.append((first[0], last[0] + (last[1] + 7) // 8 * 8))
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.compute = torch.zeros(off, dtype=BF16, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)

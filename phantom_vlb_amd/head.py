@@ -37,9 +37,12 @@ class BrainHead:
                 "ridge_layer.linear.weight": (torch.rand(num_target, dim, generator=gen) * 2 - 1) * bound,
                 "ridge_layer.linear.bias": (torch.rand(num_target, generator=gen) * 2 - 1) * bound,
             }
+            # the reference creates these modules in bf16 (dtype=self.config.dtype): start from bf16-representable values
+            sd = {n: t.to(BF16).float() for n, t in sd.items()}
         for n in HEAD_PARAMS:
-            # the reference holds these in bf16; keep the master at the bf16-rounded value for parity
-            self.master[n] = sd[n].detach().to(device=device, dtype=BF16).float().contiguous()
+            # handed-in tensors are taken as they are (bf16 checkpoints widen exactly; an fp32 checkpoint of the
+            # masters resumes at full precision)
+            self.master[n] = sd[n].detach().to(device=device, dtype=torch.float32).contiguous()
         self.compute = {n: t.to(BF16) for n, t in self.master.items()}
         self.grads = {n: torch.zeros_like(t) for n, t in self.master.items()}
         self._cap = None

@@ -26,27 +26,53 @@ from .geometry import Geometry, geometry_7b, geometry_mini
 from .head import HEAD_PARAMS, BrainHead
 from .optim import VlbAdamW
 
-try:  # real Lightning if present, else the minimal shim used by phantom_vlb_amd.trainer
-    from lightning.pytorch import LightningModule as _Base  # type: ignore
-    _HAVE_LIGHTNING = True
-except Exception:  # pragma: no cover - lightning is absent in the build image
-    _HAVE_LIGHTNING = False
 
-    class _Base:
-        def __init__(self):
-            self.training = True
-            self.logged: dict[str, float] = {}
-            self.trainer = None
+class _Base:
+    """The slice of ``lightning.pytorch.LightningModule`` the reference's module uses (``self.log``, ``self.device``,
+    train/eval mode, ``self.trainer``).  VLBLitModule deliberately does NOT subclass the real LightningModule even
+    when Lightning is installed: its backward pass is explicit (hand-written kernels, no autograd graph), which
+    Lightning's automatic optimisation cannot drive (``loss.backward()`` on a graph-less tensor) and whose manual
+    optimisation mode rejects the reference's ``gradient_clip_val``.  ``train.py`` therefore always runs the
+    built-in ``phantom_vlb_amd.trainer.Trainer`` (same YAML keys); see INTEGRATION.md."""
 
-        def log(self, name, value, **kw):
-            self.logged[name] = value
+    def __init__(self):
+        self.training = True
+        self.logged: dict[str, float] = {}
+        self.trainer = None
 
-        def train(self, mode: bool = True):
-            self.training = mode
-            return self
+    def log(self, name, value, **kw):
+        self.logged[name] = value
 
-        def eval(self):
-            return self.train(False)
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+class _LinearInfo:
+    """Stand-in for an ``nn.Linear`` leaf when a weight store lists its module tree (``Backbone.named_modules``)."""
+    is_linear = True
+
+    def __init__(self, out_features, in_features):
+        self.out_features, self.in_features = out_features, in_features
+
+
+def find_all_linear_names(model):
+    """reference :36-55 (from VideoLLaMA2's trainer): leaf names of every linear layer outside the multimodal
+    modules, minus ``lm_head`` - the LoRA ``target_modules``.  ``model`` is anything with ``named_modules()``:
+    a torch module tree (``nn.Linear`` leaves) or this package's ``Backbone`` (leaves listed from its weights)."""
+    lora_module_names = set()
+    multimodal_keywords = ["mm_projector", "vision_tower", "vision_resampler"]
+    for name, module in model.named_modules():
+        if any(k in name for k in multimodal_keywords):
+            continue
+        if isinstance(module, torch.nn.Linear) or getattr(module, "is_linear", False):
+            names = name.split(".")
+            lora_module_names.add(names[0] if len(names) == 1 else names[-1])
+    lora_module_names.discard("lm_head")
+    return sorted(lora_module_names)
 
 
 @dataclass
@@ -110,7 +136,10 @@ class VLBLitModule(_Base):
     # ------------------------------------------------------------------ model
     def configure_model(self, state_dict: dict | None = None, head_state: dict | None = None) -> None:
         """reference :206-226.  The hub checkpoint is unreachable offline: weights are
-        random-initialised on the device unless a state dict (upstream naming) is handed in."""
+        random-initialised on the device unless a state dict (upstream naming) is handed in.  Head tensors
+        (``layer_norm1.weight`` ...) and adapters (peft layout: ``...lora_A.weight`` [r,in], ``...lora_B.weight``
+        [out,r]) are taken from ``head_state`` or, when present there, from ``state_dict`` itself - so a
+        ``trainable_state_dict()`` / checkpoint ``state_dict`` merged into the backbone's loads back unchanged."""
         if getattr(self, "nnmodule", None) is not None:
             return
         cfg = self.config
@@ -131,6 +160,9 @@ class VLBLitModule(_Base):
                               f"the {cfg.geometry} architecture (no network / HF cache in this environment)")
                 state_dict = Weights.random_state_dict(g, dev, seed=cfg.init_seed)
         weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora))
+        lora_state = {k: v for k, v in state_dict.items() if ".lora_" in k} or None
+        if head_state is None and all(n in state_dict for n in HEAD_PARAMS):
+            head_state = {n: state_dict[n] for n in HEAD_PARAMS}
         del state_dict
         self.backbone = Backbone(g, weights)
         self.nnmodule = _Attr(config=_Attr(hidden_size=g.dim, tokenizer_model_max_length=g.max_len,
@@ -145,7 +177,9 @@ class VLBLitModule(_Base):
         self.lora = None
         if cfg.use_lora:
             from .lora import LoraState
-            self.lora = LoraState(g, weights, cfg.lora_r, cfg.lora_alpha, cfg.lora_dropout or 0.0, dev, seed=cfg.init_seed)
+            lora_sd = None if head_state is None and lora_state is None else {**(head_state or {}), **(lora_state or {})}
+            self.lora = LoraState(g, weights, cfg.lora_r, cfg.lora_alpha, cfg.lora_dropout or 0.0, dev, seed=cfg.init_seed,
+                                  sd=lora_sd, target_modules=find_all_linear_names(self.backbone))
 
     def trainable_named_parameters(self):
         """(name, fp32 master tensor) of everything AdamW updates: head always; LoRA A/B when use_lora
@@ -157,6 +191,37 @@ class VLBLitModule(_Base):
 
     def parameters(self):
         return [p for _, p in self.trainable_named_parameters()]
+
+    def trainable_state_dict(self) -> dict:
+        """Trainables on the host under their upstream / peft names and layouts (LoRA B as [out, r], rank padding
+        removed): what checkpoints store and what ``configure_model(state_dict=...)`` / peft accept."""
+        sd = {n: self.head.master[n].detach().cpu().clone() for n in HEAD_PARAMS}
+        if self.lora is not None:
+            sd.update({n: t.cpu() for n, t in self.lora.state_dict().items()})
+        return sd
+
+    def load_trainable_state_dict(self, sd: dict) -> None:
+        """Inverse of ``trainable_state_dict`` into the fp32 masters; bf16 copies and derived layouts are rebuilt."""
+        for n in HEAD_PARAMS:
+            self.head.master[n].copy_(sd[n].to(self.device, torch.float32))
+            self.head.compute[n].copy_(self.head.master[n])
+        if self.lora is not None:
+            self.lora.load_state_dict(sd)
+
+    # ------------------------------------------------------------------ dropout randomness (counter based)
+    def _dropout_seed(self) -> int:
+        """Head dropout seed of the current step: (init_seed, rank, step) - ranks draw different masks for their
+        clips and a resumed run continues the sequence from the restored step counter."""
+        x = (self.config.init_seed * 0x9E3779B1 + (self.rank + 1) * 0x7F4A7C15 + self._step * 0x85EBCA6B + 0x165667B1) & 0xFFFFFFFF
+        return x or 1
+
+    def rng_state(self) -> dict:
+        return {"head_step": self._step, "lora_step": None if self.lora is None else self.lora.step}
+
+    def set_rng_state(self, st: dict) -> None:
+        self._step = int(st.get("head_step", 0))
+        if self.lora is not None and st.get("lora_step") is not None:
+            self.lora.step = int(st["lora_step"])
 
     # ------------------------------------------------------------------ pieces of the step
     def make_weight_mask(self, pad_vals, vis_weights, lang_weights, lang_len, max_len):
@@ -200,14 +265,17 @@ class VLBLitModule(_Base):
                                    self.nnmodule.config.tokenizer_model_max_length)
         y = batch["timeseries"].to(dev, torch.float32).to(torch.bfloat16).float().contiguous()   # reference :288
         keep = None
-        if train and cfg.dropout_rate > 0:
-            keep = (torch.rand(x_lang.shape[0], g.dim, device=dev) >= cfg.dropout_rate).float() / (1.0 - cfg.dropout_rate)
+        if train and cfg.dropout_rate > 0:          # nn.Dropout(p) in training mode (reference :226,251)
+            keep = ops.dropout_keep_scale(x_lang.shape[0], g.dim, cfg.dropout_rate, self._dropout_seed(), dev)
         pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout)
         return pred, y, self._loss_terms
 
     def training_step(self, batch):
         """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
-        self.train(True) if not _HAVE_LIGHTNING else None
+        self.train(True)
+        self._step += 1
+        if self.lora is not None:
+            self.lora.rank = self.rank
         pred, y, terms = self._common_step(batch, train=True)
         need_dh = self.lora is not None
         inv_world = 1.0 / self.world_size
@@ -238,11 +306,8 @@ class VLBLitModule(_Base):
         if getattr(self, "flat", None) is None:
             self.flat = FlatTrainables(self)          # masters / bf16 copies / grads / moments -> flat buffers
         named = self.trainable_named_parameters()
-        bf16_copies = {n: self.head.compute[n] for n in HEAD_PARAMS}
-        if self.lora is not None:
-            bf16_copies.update(self.lora.compute_copies())
-        self.optimizer = VlbAdamW(named, bf16_copies, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
-                                  weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val, flat=self.flat)
+        self.optimizer = VlbAdamW(named, self.flat, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
+                                  weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val)
         if self.lora is not None:
             self.optimizer.post_step.append(self.lora.refresh)
         self.lr_scheduler_args = {"last_epoch": cfg.last_epoch, "T_max": cfg.t_max}

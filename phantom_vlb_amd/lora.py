@@ -76,14 +76,24 @@ GROUPS = (
 
 class LoraState:
     def __init__(self, g: Geometry, weights, r: int, alpha: int, dropout: float, device, seed: int = 1234,
-                 sd: dict | None = None):
-        if r != 16:
-            raise NotImplementedError(f"lora_r={r}: the adapter kernels are specialised for r = 16, the reference's setting "
-                                      "(config/experiment/VLB_vllama2_friends_lora.yaml:27)")
+                 sd: dict | None = None, target_modules=None):
+        """``r``: any rank 1..16 (the reference's field is a free int, litmodule :141; its YAML sets 16).  The
+        adapter kernels work on one 16-wide MFMA tile per projection, so smaller ranks are zero-padded to 16 rows:
+        padded rows of A and B^T are zero, receive exactly zero gradients (t = x.0, u = dy.0) and stay zero under
+        AdamW; ``state_dict`` / ``load_state_dict`` expose the true [r, in] / [out, r] shapes.
+        ``target_modules``: leaf names from ``find_all_linear_names`` - must be the seven decoder linears."""
+        if not isinstance(r, int) or not 1 <= r <= 16:
+            raise NotImplementedError(f"lora_r={r}: ranks 1..16 are built (one 16-wide MFMA tile per adapted projection); "
+                                      "the reference's setting is 16 (config/experiment/VLB_vllama2_friends_lora.yaml:27)")
+        want = sorted(t.split(".")[-1] for _, ts in GROUPS for t in ts)
+        if target_modules is not None and sorted(target_modules) != want:
+            raise NotImplementedError(f"LoRA target_modules {sorted(target_modules)}: the adapted decoder is built for "
+                                      f"exactly {want}")
         self.g, self.w, self.r, self.dev = g, weights, r, device
         self.scale = alpha / r
         self.p = float(dropout)
         self.step = 0
+        self.rank = 0                  # data-parallel rank, mixed into the dropout seeds (ranks draw distinct masks)
         self.grad_hook = None          # callable(layer index) fired by backward when a layer's gradients are final
         self.base_seed = seed
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
@@ -106,13 +116,16 @@ class LoraState:
                                   Bpad=torch.zeros(nout, PAD, dtype=BF16, device=device), R=R, targets=targets)
                 for j, t in enumerate(targets):
                     pre = f"model.layers.{i}.{t}"
+                    a0, b0 = torch.zeros(16, kin), torch.zeros(16, self.out_dims[t])
                     if sd is not None and f"{pre}.lora_A.weight" in sd:
-                        a0 = sd[f"{pre}.lora_A.weight"].float()
-                        b0 = sd[f"{pre}.lora_B.weight"].float().t().contiguous()
+                        a_in, b_in = sd[f"{pre}.lora_A.weight"].float(), sd[f"{pre}.lora_B.weight"].float()
+                        if tuple(a_in.shape) != (r, kin) or tuple(b_in.shape) != (self.out_dims[t], r):
+                            raise ValueError(f"{pre}: adapter shapes {tuple(a_in.shape)}/{tuple(b_in.shape)} do not match "
+                                             f"lora_r={r} (peft layout: lora_A [r,in], lora_B [out,r])")
+                        a0[:r], b0[:r] = a_in, b_in.t()
                     else:
                         bound = 1.0 / math.sqrt(kin)           # kaiming_uniform(a=sqrt(5))
-                        a0 = (torch.rand(16, kin, generator=gen) * 2 - 1) * bound
-                        b0 = torch.zeros(16, self.out_dims[t])
+                        a0[:r] = (torch.rand(16, kin, generator=gen)[:r] * 2 - 1) * bound
                     self.master[f"{pre}.lora_A.weight"] = a0.to(device).contiguous()
                     self.master[f"{pre}.lora_B.weight"] = b0.to(device).contiguous()    # stored as B^T [r,out]
             self.layers.append(lay)
@@ -183,11 +196,21 @@ class LoraState:
         check(lib.vlb_transpose16_scatter(jobs.data_ptr(), self._n_jobs, _stream()), "vlb_transpose16_scatter")
 
     def state_dict(self):
-        """peft layout: lora_A [r,in], lora_B [out,r]."""
-        return {n: (t.t().contiguous() if "lora_B" in n else t.clone()) for n, t in self.master.items()}
+        """peft layout: lora_A [r,in], lora_B [out,r] (rank padding removed)."""
+        r = self.r
+        return {n: (t[:r].t().contiguous() if "lora_B" in n else t[:r].clone()) for n, t in self.master.items()}
+
+    def load_state_dict(self, sd: dict):
+        """peft-layout tensors -> fp32 masters (padded rows stay zero), then bf16 copies + derived layouts."""
+        r = self.r
+        for n, t in self.master.items():
+            src = sd[n].to(self.dev, torch.float32)
+            t[:r].copy_(src.t() if "lora_B" in n else src)
+        self.refresh(from_master=True)
 
     def _seed(self, layer, target_idx):
-        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA6B + layer * 0xC2B2AE35 + target_idx * 0x27D4EB2F) & 0xFFFFFFFF
+        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA6B + layer * 0xC2B2AE35 + target_idx * 0x27D4EB2F
+             + self.rank * 0x7F4A7C15) & 0xFFFFFFFF
         return x or 1
 
     def _workspace(self, M):

@@ -378,6 +378,14 @@ def weight_mask(padvals, vis_w, lang_w, tokens_per_frame, S, round_bf16=True):
     return out
 
 
+def dropout_keep_scale(B, E, p, seed, device):
+    """fp32 [B,E] of keep/(1-p): the head's nn.Dropout(p) mask as a counter-based hash of (seed, position)."""
+    out = torch.empty(B, E, dtype=torch.float32, device=device)
+    check(lib.vlb_dropout_keep_scale(_dev(out).data_ptr(), out.numel(), float(p), int(seed) & 0xFFFFFFFF, _stream()),
+          "vlb_dropout_keep_scale")
+    return out
+
+
 def cast_bf16(x_f32):
     out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
     check(lib.vlb_cast_f32_to_bf16(_dev(x_f32).data_ptr(), out.data_ptr(), x_f32.numel(), _stream()), "vlb_cast_f32_to_bf16")

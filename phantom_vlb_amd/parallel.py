@@ -56,83 +56,179 @@ def dp_loss_scales(world: int):
     return 1.0 / world, 1.0 / world
 
 
-class FlatGradReducer:
-    """Re-points a set of gradient tensors into one flat buffer and all-reduces it in one call."""
+class TorchComm:
+    """The three collectives the sharded step needs, over torch.distributed (backend "nccl" = RCCL on ROCm, gloo on
+    CPU).  ``parallel_native.DirectComm`` offers the same interface on libvlb's own RCCL entry points
+    (vlb_comm_* in include/vlb.h: all-pairs schedules over the xGMI links)."""
 
-    def __init__(self, grad_dicts: list[dict], group=None):
+    def __init__(self, group=None):
         self.group = group
-        items = [(d, k) for d in grad_dicts for k in d]
-        total = sum(d[k].numel() for d, k in items)
-        ref = items[0][0][items[0][1]]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        self._pending = []
-        off = 0
-        for d, k in items:
-            n = d[k].numel()
-            view = self.flat[off:off + n].view(d[k].shape)
-            view.copy_(d[k])
-            d[k] = view                     # kernels write straight into the bucket from now on
-            off += n
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
-    force = False     # rehearsal switch: reduce even when the group has a single rank
+    def reduce_scatter(self, out, inp):
+        """out[n/world] = sum over ranks of inp[rank*n/world : ...]; asynchronous, returns a handle with wait()."""
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _active(self):
-        return dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+    def all_gather(self, out, inp):
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
-    def reduce_range(self, start: int, end: int):
-        """Start the all-reduce of flat[start:end] NOW (asynchronously): called from the backward pass as soon as
-        a range of layers has its final gradients, so the exchange over xGMI overlaps the rest of backward.
-        The collective is ordered after everything already enqueued on the current stream."""
-        if not self._active() or end <= start:
+    def all_reduce_scalar(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedFlatState:
+    """fsdp.yaml's FULL_SHARD for everything the optimiser owns (reference fsdp.yaml:5-14, never loaded by its
+    mainline): the flat trainables of ``flat.FlatTrainables`` are cut into segments (the head; runs of whole decoder
+    layers) and every rank owns the rank-th 1/world slice of each segment.
+
+    Per step and segment: ``reduce_scatter`` of the fp32 gradient (started from the backward pass the moment the
+    segment's layers are differentiated, so the xGMI exchange runs under the remaining backward) -> each rank holds
+    the summed gradient of its slice only; the clip norm is the all-reduced sum of the slices' squares; AdamW runs
+    on the slice (fp32 master and both moments exist ONLY for the owned slice: 16 B/param/world); the updated bf16
+    compute copies are ``all_gather``-ed back into the full buffer the kernels read.  Wire bytes per step:
+    (world-1)/world x (4 + 2) B per trainable, against 8 B for the all-reduce of replicated optimisers.
+    At world 1 the slices ARE the flat buffers (aliases, no copies, no collectives): one code path.
+
+    ``flat.master`` stays allocated at full size as a staging area: ``gather_masters()`` refreshes it (checkpoints,
+    tests) and ``load_masters()`` re-reads the owned slices from it (resume, sync_module_states)."""
+
+    NAMES = ("master", "grad", "m", "v")
+
+    def __init__(self, flat, comm=None, chunks: int = 4, force_collectives: bool = False):
+        """``force_collectives``: run the collective path (separate shard buffers, reduce-scatter / all-gather calls)
+        even at world size 1 - rehearses the RCCL calls on a one-GPU box."""
+        self.flat = flat
+        self.comm = comm if comm is not None else TorchComm()
+        w, r = self.comm.world, self.comm.rank
+        self.world, self.rank = w, r
+        segs = [flat.head_range]
+        L = len(flat.layer_ranges)
+        per = max(1, -(-L // chunks)) if L else 1
+        self.layer_seg = {}                       # first layer of a chunk -> segment index
+        for lo in range(0, L, per):
+            hi = min(lo + per, L) - 1
+            self.layer_seg[lo] = len(segs)
+            segs.append((flat.layer_ranges[lo][0], flat.layer_ranges[hi][1]))
+        for s, e in segs:
+            if (e - s) % (8 * w):
+                raise ValueError(f"world size {w} does not divide the flat segment alignment ({e - s} elements): "
+                                 f"supported world sizes divide 840 (1..8, 10, 12, ...)")
+        self.segments = segs
+        self.shard_off, off = [], 0
+        for s, e in segs:
+            self.shard_off.append(off)
+            off += (e - s) // w
+        self.numel = off
+        assert off * w == flat.numel
+        self.active = w > 1 or (force_collectives and dist.is_initialized())
+        if not self.active:
+            self.master, self.compute, self.grad, self.m, self.v = flat.master, flat.compute, flat.grad, flat.m, flat.v
+        else:
+            dev = flat.master.device
+            self.master = torch.empty(off, dtype=torch.float32, device=dev)
+            self.compute = torch.empty(off, dtype=flat.compute.dtype, device=dev)
+            self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.load_masters()
+            flat.m = flat.v = None                # the full-size moments are released: sharded state only
+        self._pending = {}
+
+    def _own(self, si):
+        """(slice of the flat buffers this rank owns in segment si, its slice of the shard buffers)."""
+        s, e = self.segments[si]
+        n = (e - s) // self.world
+        return slice(s + self.rank * n, s + (self.rank + 1) * n), slice(self.shard_off[si], self.shard_off[si] + n)
+
+    # ---- gradients
+    def reduce_segment(self, si: int):
+        """Start the reduce-scatter of segment si NOW (ordered after everything enqueued on the current stream)."""
+        if not self.active or si in self._pending:
             return
-        work = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((start, end, work))
+        s, e = self.segments[si]
+        _, mine = self._own(si)
+        self._pending[si] = self.comm.reduce_scatter(self.grad[mine], self.flat.grad[s:e])
 
-    def __call__(self, grads=None):
-        """Finish the step's reduction: ranges already started are waited for, the rest is reduced in as few
-        calls as possible (one, when nothing was started early)."""
-        if not self._active():
-            return
-        done = sorted((s, e) for s, e, _ in self._pending)
-        pos, n = 0, self.flat.numel()
-        for s, e in done + [(n, n)]:
-            if s > pos:
-                self._pending.append((pos, s, dist.all_reduce(self.flat[pos:s], op=dist.ReduceOp.SUM, group=self.group,
-                                                             async_op=True)))
-            pos = max(pos, e)
-        for _, _, work in self._pending:
+    def on_layer_done(self, li: int):
+        """LoRA / full backward hook: layer li (walking L-1 .. 0) has its final gradients."""
+        si = self.layer_seg.get(li)
+        if si is not None:
+            self.reduce_segment(si)
+
+    def finish_reduce(self):
+        for si in range(len(self.segments)):
+            self.reduce_segment(si)
+        for work in self._pending.values():
             work.wait()
-        self._pending = []
+        self._pending = {}
 
-    _pending: list = []
+    def all_reduce_scalar(self, t):
+        if self.active:
+            self.comm.all_reduce_scalar(t)
+
+    # ---- parameters
+    def gather_compute(self):
+        """After the update: every rank's refreshed bf16 slices -> the full compute buffer the kernels read."""
+        if not self.active:
+            return
+        works = []
+        for si, (s, e) in enumerate(self.segments):
+            works.append(self.comm.all_gather(self.flat.compute[s:e], self.compute[self._own(si)[1]]))
+        for wk in works:
+            wk.wait()
+
+    def gather_full(self, name: str):
+        """Full-size fp32 copy of a sharded buffer ('master' | 'grad' | 'm' | 'v') on every rank (checkpoints, tests)."""
+        src = getattr(self, name)
+        if not self.active:
+            return src
+        out = torch.empty(self.flat.numel, dtype=src.dtype, device=src.device)
+        works = [self.comm.all_gather(out[s:e], src[self._own(si)[1]]) for si, (s, e) in enumerate(self.segments)]
+        for wk in works:
+            wk.wait()
+        return out
+
+    def gather_masters(self):
+        if self.active:
+            self.flat.master.copy_(self.gather_full("master"))
+
+    def load_full(self, name: str, full):
+        if not self.active:
+            getattr(self, name).copy_(full)
+            return
+        dst = getattr(self, name)
+        for si in range(len(self.segments)):
+            whole, mine = self._own(si)
+            dst[mine].copy_(full[whole])
+
+    def load_masters(self):
+        """Owned master slices <- flat.master (after a checkpoint load / broadcast wrote the full buffer)."""
+        if self.active:
+            self.load_full("master", self.flat.master)
 
 
-def attach_data_parallel(module, optimizer, group=None):
-    """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism."""
-    flat = getattr(module, "flat", None)
-    if flat is not None:                     # the optimiser's flat gradient buffer IS the bucket
-        reducer = FlatGradReducer.__new__(FlatGradReducer)
-        reducer.group, reducer.flat, reducer._pending = group, flat.grad, []
-        lora = getattr(module, "lora", None)
-        if lora is not None and getattr(flat, "layer_ranges", None):
-            # overlap: when backward has finished layers [li, li+chunk) their slice of the bucket is reduced while
-            # the layers below are still being differentiated (backward walks li = L-1 .. 0)
-            chunk = max(1, len(flat.layer_ranges) // 4)
+def attach_data_parallel(module, optimizer, group=None, comm=None, force_collectives: bool = False):
+    """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism with sharded optimiser state."""
+    flat = module.flat
+    if comm is None:
+        comm = make_comm(group)
+    state = ShardedFlatState(flat, comm, force_collectives=force_collectives)
+    optimizer.attach_sharded(state)
+    for owner in (getattr(module, "lora", None), getattr(module, "full", None)):
+        if owner is not None:
+            owner.grad_hook = state.on_layer_done
+    module.world_size, module.rank = state.world, state.rank
+    module.sharded = state
+    return state
 
-            def on_layer_done(li, ranges=flat.layer_ranges, chunk=chunk):
-                if li % chunk == 0:
-                    hi = min(li + chunk, len(ranges)) - 1
-                    reducer.reduce_range(ranges[li][0], ranges[hi][1])
-            lora.grad_hook = on_layer_done
-    else:
-        dicts = [module.head.grads]
-        if getattr(module, "lora", None) is not None:
-            dicts.append(module.lora.grads)
-        reducer = FlatGradReducer(dicts, group)
-    optimizer.grad_reducer = reducer
-    module.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
-    module.rank = dist.get_rank(group) if dist.is_initialized() else 0
-    return reducer
+
+def make_comm(group=None):
+    """VLB_COMM=direct selects libvlb's own RCCL schedules (vlb_comm_*); default: torch.distributed."""
+    if os.environ.get("VLB_COMM", "torch") == "direct" and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        from .parallel_native import DirectComm
+        return DirectComm(group)
+    return TorchComm(group)
 
 
 def broadcast_parameters(tensors, src: int = 0, group=None):
@@ -149,6 +245,9 @@ def sync_module_states(module, src: int = 0, group=None):
     if flat is not None:
         broadcast_parameters([flat.master], src, group)
         flat.compute.copy_(flat.master)
+        sharded = getattr(module, "sharded", None)
+        if sharded is not None:
+            sharded.load_masters()
     else:
         broadcast_parameters(module.parameters(), src, group)
         for n, t in module.head.master.items():

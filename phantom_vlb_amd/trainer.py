@@ -34,6 +34,43 @@ class CSVLogger:
             w.writerows(self.rows)
 
 
+class LearningRateMonitor:
+    """``lightning.pytorch.callbacks.LearningRateMonitor(logging_interval=...)`` (reference train.py:28): logs the
+    optimiser's learning rate under Lightning's key ``lr-AdamW`` every epoch (or every logged step)."""
+
+    def __init__(self, logging_interval="epoch", **kw):
+        self.logging_interval = logging_interval
+
+    def on_train_epoch_start(self, trainer, module):
+        if self.logging_interval != "step":
+            trainer._log({"lr-AdamW": module.optimizer.param_groups[0]["lr"]})
+
+    def on_train_batch_start(self, trainer, module, batch, batch_idx):
+        if self.logging_interval == "step" and trainer.global_step % trainer.log_every_n_steps == 0:
+            trainer._log({"lr-AdamW": module.optimizer.param_groups[0]["lr"]})
+
+
+def trainable_state(module, step: int) -> dict:
+    """Everything a bit-exact resume needs, trainables only (head + LoRA / trained backbone tensors), gathered from
+    the shards under data parallelism (a collective: call on every rank).  ``state_dict`` uses the upstream / peft
+    layouts (``lora_B.weight`` is [out, r]) so it can be handed to ``configure_model(state_dict=...)`` or to peft."""
+    opt = getattr(module, "optimizer", None)
+    sharded = getattr(module, "sharded", None)
+    if sharded is not None:
+        sharded.gather_masters()
+    sd = module.trainable_state_dict()
+    state = {"state_dict": sd, "global_step": step, "format": 2}
+    if opt is not None:
+        state.update(exp_avg=opt.full_state("m").cpu(), exp_avg_sq=opt.full_state("v").cpu(), opt_step=opt.step_count,
+                     flat_offsets={n: (o, k) for n, (o, k, _) in module.flat.offsets.items()},
+                     lr=opt.param_groups[0]["lr"])
+    sch = getattr(module, "scheduler", None)
+    if sch is not None:
+        state["lr_scheduler"] = sch.state_dict()
+    state["rng"] = module.rng_state()
+    return state
+
+
 class TrainableCheckpoint:
     """ModelCheckpoint(monitor="val/brain_loss", mode="min", save_last=True) for the TRAINABLE tensors only
     (head + LoRA) - the reference saves the whole frozen 7B each time and notes the TODO (train.py:21-27,60)."""
@@ -43,15 +80,10 @@ class TrainableCheckpoint:
         self.best = None
 
     def save(self, module, path, step):
+        state = trainable_state(module, step)       # gathers the shards: every rank takes part
         if int(os.environ.get("RANK", "0")) != 0:
-            return                      # data parallel: the trainables are replicated, rank 0 writes the one file
+            return                      # data parallel: rank 0 writes the one file
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        sd = {n: p.detach().cpu() for n, p in module.trainable_named_parameters()}
-        opt = getattr(module, "optimizer", None)
-        state = {"state_dict": sd, "global_step": step}
-        if opt is not None:
-            state.update(exp_avg=[m.cpu() for m in opt.m], exp_avg_sq=[v.cpu() for v in opt.v], opt_step=opt.step_count,
-                         lr=opt.param_groups[0]["lr"])
         torch.save(state, path)
 
     def on_validation_end(self, trainer, module, metrics):
@@ -68,21 +100,23 @@ class TrainableCheckpoint:
 
 
 def load_trainable_checkpoint(module, path):
-    """Resume: restore trainables, Adam moments and the step counter."""
-    st = torch.load(path, map_location="cpu")
-    for n, p in module.trainable_named_parameters():
-        p.copy_(st["state_dict"][n].to(p.device))
+    """Resume: trainables, Adam moments and step count, LR-scheduler state, and the dropout counters / generator
+    (LoRA's counter-based seed, the head's mask generator) - so the resumed run replays neither LR nor masks."""
+    st = torch.load(path, map_location="cpu", weights_only=False)
+    module.load_trainable_state_dict(st["state_dict"])
     opt = getattr(module, "optimizer", None)
     if opt is not None and "exp_avg" in st:
-        for m, s in zip(opt.m, st["exp_avg"]):
-            m.copy_(s.to(m.device))
-        for v, s in zip(opt.v, st["exp_avg_sq"]):
-            v.copy_(s.to(v.device))
+        opt.load_full_state("master", module.flat.master)
+        opt.load_full_state("m", st["exp_avg"])
+        opt.load_full_state("v", st["exp_avg_sq"])
         opt.step_count = st["opt_step"]
-    for n in module.head.master:
-        module.head.compute[n].copy_(module.head.master[n])
-    if module.lora is not None:
-        module.lora.refresh(from_master=True)
+    sch = getattr(module, "scheduler", None)
+    if sch is not None and "lr_scheduler" in st:
+        sch.load_state_dict(st["lr_scheduler"])
+        if opt is not None:
+            opt.param_groups[0]["lr"] = st["lr"]
+    if "rng" in st:
+        module.set_rng_state(st["rng"])
     return st.get("global_step", 0)
 
 
@@ -120,15 +154,33 @@ class Trainer:
                 lg.log_metrics(metrics, self.global_step)
 
     def validate(self, model, loader):
+        """Validation epoch.  Data parallel: ranks take rank-strided batches (the frozen weights are replicated, so
+        a validation forward needs no collective), and the loss sum / batch count / Pearson sums are all-reduced
+        once at the end; with sharded frozen weights (per-layer all-gathers in every forward) all ranks keep
+        running every batch so their collective sequences stay aligned."""
         self._cb("on_validation_epoch_start", model)
         tot, n = None, 0                     # summed on the device: one host sync per validation epoch, not per batch
+        strided = self.world > 1 and getattr(model.backbone, "store", None) is None
         for bi, batch in enumerate(loader):
             if self.limit_val_batches is not None and bi >= self.limit_val_batches:
                 break
+            if strided and bi % self.world != self.rank:
+                continue
             out = model.validation_step(batch)
             self._cb("on_validation_batch_end", model, out, batch, bi)
             tot = out["loss"].detach().double() if tot is None else tot + out["loss"].detach().double()
             n += 1
+        if strided:
+            import torch.distributed as dist
+            t = torch.zeros(2, dtype=torch.float64, device=model.device)
+            if tot is not None:
+                t[0] = tot
+            t[1] = n
+            dist.all_reduce(t)
+            tot, n = t[0], int(t[1].item())
+            for c in self.callbacks:
+                if hasattr(c, "all_reduce_sums"):
+                    c.all_reduce_sums()
         self._cb("on_validation_epoch_end", model)
         metrics = {"val/brain_loss": (float(tot) if tot is not None else 0.0) / max(n, 1)}
         metrics.update({k: float(v) for k, v in getattr(model, "logged", {}).items() if k.startswith("val_corr_avg")})
@@ -139,6 +191,8 @@ class Trainer:
         return metrics
 
     def fit(self, model, datamodule=None, ckpt_path=None):
+        self.model = model
+        model.trainer = self
         model.configure_model()
         model.config.gradient_clip_val = self.gradient_clip_val
         opts, scheds = model.configure_optimizers()
@@ -162,10 +216,15 @@ class Trainer:
         n_batches = len(train_loader)
         val_every = max(1, int(n_batches * self.val_check_interval)) if self.val_check_interval <= 1 else int(self.val_check_interval)
         t0 = time.time()
-        for epoch in range(self.max_epochs):
+        start_epoch, skip = divmod(self.global_step, max(n_batches, 1)) if ckpt_path else (0, 0)
+        for epoch in range(start_epoch, self.max_epochs):
             if hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
+            self._cb("on_train_epoch_start", model)
             for bi, batch in enumerate(train_loader):
+                if epoch == start_epoch and bi < skip:
+                    continue                  # resumed mid-epoch: these batches were consumed before the checkpoint
+                self._cb("on_train_batch_start", model, batch, bi)
                 loss = model.training_step(batch)
                 opt.step()
                 sched.step()
@@ -179,5 +238,13 @@ class Trainer:
                     return
         return
 
-    def save_checkpoint(self, path):
-        pass
+    def save_checkpoint(self, filepath, weights_only: bool = False):
+        """``trainer.save_checkpoint(config.output_dir)`` (reference train.py:58).  The reference passes the output
+        DIRECTORY; Lightning would try to write a file of that name - here a directory gets ``final.ckpt`` inside."""
+        model = getattr(self, "model", None)
+        if model is None:
+            raise RuntimeError("save_checkpoint() before fit(): no module attached")
+        if os.path.isdir(filepath) or not os.path.splitext(filepath)[1]:
+            filepath = os.path.join(filepath, "final.ckpt")
+        TrainableCheckpoint(os.path.dirname(filepath)).save(model, filepath, self.global_step)
+        return filepath

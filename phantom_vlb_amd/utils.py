@@ -11,11 +11,10 @@ import torch
 
 from . import ops
 
-try:
-    from lightning.pytorch.callbacks import Callback as _Callback  # type: ignore
-except Exception:  # pragma: no cover
-    class _Callback:
-        pass
+
+class _Callback:
+    """Hook-name compatible stand-in for ``lightning.pytorch.callbacks.Callback`` (the built-in Trainer calls hooks by
+    name; the real base class is never needed - see litmodule._Base)."""
 
 
 def get_hrf_weight(time_diff: float) -> float:
@@ -86,6 +85,16 @@ class LogValAccuracyCallback(_Callback):
         cur = torch.stack([p.sum(0), y.sum(0), (p * p).sum(0), (y * y).sum(0), (p * y).sum(0)])
         self.s = cur if self.s is None else self.s + cur
         self.n += p.shape[0]
+
+    def all_reduce_sums(self):
+        """Data parallel validation (rank-strided batches): sum the running sums over ranks, once per epoch."""
+        import torch.distributed as dist
+        if self.s is None:
+            return
+        n = torch.tensor([float(self.n)], dtype=torch.float64, device=self.s.device)
+        dist.all_reduce(self.s)
+        dist.all_reduce(n)
+        self.n = int(n.item())
 
     def on_validation_epoch_end(self, trainer, pl_module):
         if self.s is None:

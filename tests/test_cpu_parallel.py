@@ -1,5 +1,6 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: flat gradient bucket all-reduce,
-loss scaling identity, and the sharded-layer store's gather/prefetch in both directions."""
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: reduce-scatter / slice update / all-gather of the
+sharded flat optimiser state, the loss scaling identity, and the sharded-layer store's gather/prefetch in both
+directions."""
 import os
 import sys
 
@@ -31,52 +32,83 @@ def _run(fn, world=2):
     return dict(ret)
 
 
-def _flat_reduce(rank, world):
-    from phantom_vlb_amd.parallel import FlatGradReducer
-    torch.manual_seed(rank)
-    a = {"w": torch.randn(7, 5), "b": torch.randn(5)}
-    b = {"l": torch.randn(16, 9)}
-    before = {**{k: v.clone() for k, v in a.items()}, **{k: v.clone() for k, v in b.items()}}
-    red = FlatGradReducer([a, b])
-    assert red.flat.numel() == 35 + 5 + 144
-    assert a["w"].data_ptr() == red.flat.data_ptr()          # views, not copies
-    a["b"].add_(1.0)                                         # a kernel writing a grad writes the bucket
-    red()
-    return {k: v.clone() for k, v in {**a, **b}.items()}, before
+class _FakeFlat:
+    """CPU stand-in for flat.FlatTrainables: the five flat buffers + the segment table ShardedFlatState reads."""
+
+    def __init__(self, layers=4, head=6720, per_layer=6720 * 2, seed=0):
+        n = head + layers * per_layer
+        gen = torch.Generator().manual_seed(seed)
+        self.numel = n
+        self.master = torch.randn(n, generator=gen)
+        self.compute = self.master.bfloat16()
+        self.grad = torch.zeros(n)
+        self.m, self.v = torch.zeros(n), torch.zeros(n)
+        self.head_range = (0, head)
+        self.layer_ranges = [(head + i * per_layer, head + (i + 1) * per_layer) for i in range(layers)]
 
 
-def test_flat_grad_reducer_sums_over_ranks():
-    out = _run(_flat_reduce)
-    (g0, b0), (g1, b1) = out[0], out[1]
-    for k in g0:
-        expect = b0[k] + b1[k] + (2.0 if k == "b" else 0.0)
-        assert torch.allclose(g0[k], expect) and torch.allclose(g1[k], expect)
+def _sharded_state(rank, world):
+    """reduce-scatter under 'backward' (two layer chunks started early) + the rest at finish: every rank ends up with
+    the summed gradient of exactly its slices; a slice-local update + all-gather rebuilds identical full bf16 copies;
+    masters round-trip through gather / load."""
+    from phantom_vlb_amd.parallel import ShardedFlatState
+    flat = _FakeFlat()
+    st = ShardedFlatState(flat, chunks=2)
+    assert st.world == world and st.numel * world == flat.numel and flat.m is None
+    assert len(st.segments) == 3 and st.layer_seg == {0: 1, 2: 2}
+    torch.manual_seed(100 + rank)
+    flat.grad.copy_(torch.randn(flat.numel))
+    local = flat.grad.clone()
+    for li in (3, 2):                 # backward walks down: chunk [2,3] is final when layer 2 is done
+        st.on_layer_done(li)
+    assert list(st._pending) == [2]
+    st.on_layer_done(1)
+    st.on_layer_done(0)
+    st.finish_reduce()
+    summed = st.gather_full("grad")
+    # "optimiser": master_slice -= 0.5 * grad_slice, bf16 copy refreshed, then gathered
+    st.master.sub_(0.5 * st.grad)
+    st.compute.copy_(st.master)
+    st.gather_compute()
+    st.gather_masters()
+    m_after = flat.master.clone()
+    # masters: scramble the staging copy's foreign slices, reload own slices, gather again -> unchanged
+    st.load_masters()
+    st.gather_masters()
+    return local, summed, m_after, flat.compute.float().clone(), flat.master.clone()
 
 
-def _flat_reduce_overlapped(rank, world):
-    """Ranges started early (as backward finishes layer groups) + the final call == one whole-bucket reduce,
-    every element reduced exactly once."""
-    from phantom_vlb_amd.parallel import FlatGradReducer
-    torch.manual_seed(10 + rank)
-    grads = {f"t{i}": torch.randn(11 + i) for i in range(9)}
-    before = torch.cat([v.reshape(-1) for v in grads.values()]).clone()
-    red = FlatGradReducer([grads])
-    n = red.flat.numel()
-    red.reduce_range(n - 30, n)             # "layers 24..31"
-    red.reduce_range(40, n - 30)            # "layers 8..23"
-    red.reduce_range(40, 40)                # empty range: ignored
-    red()                                   # head + the remaining prefix, then waits
-    assert red._pending == []
-    red2 = red.flat.clone()
-    red()                                   # a second call with nothing started reduces the whole bucket once more
-    return red2, red.flat.clone(), before
+def test_sharded_flat_state_reduce_scatter_update_all_gather():
+    out = _run(_sharded_state)
+    ref = _FakeFlat()
+    total = out[0][0] + out[1][0]
+    for r in (0, 1):
+        local, summed, m_after, comp, m_again = out[r]
+        assert torch.allclose(summed, total)
+        assert torch.allclose(m_after, ref.master - 0.5 * total, atol=1e-6)
+        assert torch.equal(comp, m_after.bfloat16().float())
+        assert torch.equal(m_again, m_after)
+    assert torch.equal(out[0][2], out[1][2])
 
 
-def test_flat_grad_reducer_overlapped_ranges():
-    out = _run(_flat_reduce_overlapped)
-    (r0, again0, b0), (r1, again1, b1) = out[0], out[1]
-    assert torch.allclose(r0, b0 + b1) and torch.allclose(r1, b0 + b1)          # each element exactly once
-    assert torch.allclose(again0, 2 * (b0 + b1)) and torch.allclose(again1, again0)
+def test_sharded_flat_state_world_one_aliases_the_flat_buffers():
+    from phantom_vlb_amd.parallel import ShardedFlatState
+    flat = _FakeFlat()
+    st = ShardedFlatState(flat)
+    assert st.world == 1 and not st.active
+    assert st.master.data_ptr() == flat.master.data_ptr() and st.grad.data_ptr() == flat.grad.data_ptr()
+    st.on_layer_done(0); st.finish_reduce(); st.gather_compute()        # all no-ops
+    assert st.gather_full("m") is flat.m
+
+
+def test_sharded_flat_state_rejects_world_sizes_that_do_not_divide_the_segments():
+    import pytest
+    from phantom_vlb_amd.parallel import ShardedFlatState
+
+    class _Comm:
+        world, rank = 11, 0
+    with pytest.raises(ValueError):
+        ShardedFlatState(_FakeFlat(), comm=_Comm())
 
 
 def _dp_identity(rank, world):
@@ -84,7 +116,7 @@ def _dp_identity(rank, world):
     concatenated batch (ridge penalty counted once) - checked with the oracle's head on CPU."""
     import vlb_oracle as O
     import torch.nn.functional as F
-    from phantom_vlb_amd.parallel import FlatGradReducer, dp_loss_scales
+    from phantom_vlb_amd.parallel import dp_loss_scales
     g = O.Geometry(dim=32, num_target=16, l2_lambda=1e-2)
     gen = torch.Generator().manual_seed(0)
     p = {"layer_norm1.weight": torch.ones(32), "layer_norm1.bias": torch.zeros(32), "layer_norm2.weight": torch.ones(32),
@@ -101,8 +133,8 @@ def _dp_identity(rank, world):
     ms, ls = dp_loss_scales(world)
     sl = slice(rank * 2, rank * 2 + 2)
     mine = grads(hidden[sl], wm[sl], y[sl], ms, ls)
-    red = FlatGradReducer([mine])
-    red()
+    for k in mine:
+        dist.all_reduce(mine[k])
     return max(float((mine[k] - full[k]).abs().max()) for k in full)
 
 

@@ -1,6 +1,7 @@
-"""2-rank data parallelism on ONE GPU (gloo backend, both ranks on cuda:0): the summed, 1/world-scaled
-gradients equal the single-process gradients on the concatenated batch, and one optimiser step leaves
-both ranks with identical parameters.  Exercises bench.py's N>1 code path (FlatTrainables bucket)."""
+"""2-rank data parallelism on ONE GPU (gloo backend, both ranks on cuda:0): the reduce-scattered, 1/world-scaled
+gradients equal the single-process gradients on the concatenated batch, and one sharded optimiser step (each rank
+updates its half of every segment, bf16 copies all-gathered) leaves both ranks with the single-process parameters.
+Exercises bench.py's N>1 code path (parallel.ShardedFlatState), and `python bench.py --gpus 2` launching itself."""
 import os
 import sys
 
@@ -44,21 +45,23 @@ def _worker(rank, world, port, lora, ret):
             opt, _ = m.configure_optimizers()
             return m, opt[0]
         m, opt = build()
-        attach_data_parallel(m, opt)
-        assert m.world_size == 2
+        st = attach_data_parallel(m, opt)
+        assert m.world_size == 2 and st.active and st.numel * 2 == m.flat.numel and m.flat.m is None
         mine = {k: v[rank * 2:rank * 2 + 2] for k, v in full.items()}
         m.training_step(mine)
-        opt.grad_reducer()
-        g_dp = m.flat.grad.clone()
-        opt.grad_reducer = None           # already reduced above
-        opt.step()
+        opt.step()                        # finish reduce-scatter, clip over both ranks' slices, AdamW on the slice, all-gather
+        g_dp = st.gather_full("grad")
+        st.gather_masters()
         torch.cuda.synchronize()
-        out = {"master": m.flat.master.cpu()}
+        out = {"master": m.flat.master.cpu(), "compute": m.flat.compute.float().cpu()}
         if rank == 0:
-            ref, _ = build()
+            ref, ropt = build()
             ref.training_step(full)
-            g_ref = ref.flat.grad
+            g_ref = ref.flat.grad.clone()
+            ropt.step()
+            torch.cuda.synchronize()
             out["err"] = float((g_dp - g_ref).abs().max() / g_ref.abs().max())
+            out["perr"] = float((m.flat.master - ref.flat.master).abs().max())
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -71,4 +74,29 @@ def test_two_rank_gradients_match_single_process(dev, lora):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29600 + random.randint(0, 2000), lora, ret), nprocs=2, join=True)
     assert ret[0]["err"] < (4e-2 if lora else 2e-2), ret[0]["err"]        # bf16 activations, different batch split
+    assert ret[0]["perr"] < 2.5e-3, ret[0]["perr"]                         # one AdamW step of lr 1e-3: |update| <= lr
     assert torch.equal(ret[0]["master"], ret[1]["master"])                 # ranks stay in lock-step
+    assert torch.equal(ret[0]["compute"], ret[1]["compute"])
+
+
+def test_bench_gpus_2_launches_two_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher: two ranks are started (time-sharing this GPU over gloo), rank 0
+    prints ONE JSON line with n_gpus 2; asking for more RCCL ranks than GPUs fails instead of running fewer."""
+    import json
+    import subprocess
+    env = dict(os.environ, VLB_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "mini", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["clips_per_gpu"]
+    assert "world=2" in out["config"]["comm"]
+    env.pop("VLB_DIST_BACKEND")
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "mini"],
+                           capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout

@@ -476,3 +476,24 @@ def test_gemm_split_k_tail_swiglu_pair(dev):
     out = ops.gemm(a, ops.interleave_gate_up(wg, wu), act=ops.ACT_SWIGLU_PAIR)
     ref = F.silu(a.float() @ wg.float().t()) * (a.float() @ wu.float().t())
     assert rel_err(out, ref) < 8e-3
+
+
+def test_head_dropout_keep_scale_statistics_and_determinism(dev):
+    """vlb_dropout_keep_scale: values are exactly 0 or 1/(1-p), keep rate p within binomial noise, a pure function
+    of (seed, position), different seeds decorrelated."""
+    from phantom_vlb_amd import ops
+    B, E, p = 64, 4096, 0.1
+    a = ops.dropout_keep_scale(B, E, p, 1234, dev)
+    b = ops.dropout_keep_scale(B, E, p, 1234, dev)
+    c = ops.dropout_keep_scale(B, E, p, 1235, dev)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    keep = (a > 0).float()
+    assert abs(float(keep.mean()) - (1 - p)) < 2e-3            # sigma = sqrt(.09/262144) = 6e-4
+    agree = float(((a > 0) == (c > 0)).float().mean())
+    assert abs(agree - (0.81 + 0.01)) < 5e-3                   # independent masks agree with prob p^2 + (1-p)^2
+    rows = keep.mean(1)
+    assert float(rows.std()) < 3 * (0.09 / E) ** 0.5 + 1e-3
+    odd = ops.dropout_keep_scale(3, 5, 0.5, 7, dev)            # odd element count: the tail element is written
+    assert odd.shape == (3, 5) and torch.isfinite(odd).all() and set(torch.unique(odd).tolist()) <= {0.0, 2.0}

@@ -39,33 +39,70 @@ def test_train_py_mini_experiment(tmp_path):
                                      "ridge_layer.linear.weight", "ridge_layer.linear.bias"}      # trainables only
 
 
-def test_checkpoint_resume_is_exact(dev, tmp_path):
-    """3 steps, save, 2 more steps  ==  load the checkpoint into a fresh module and do the same 2 steps."""
+def _dm(batch_size=2):
+    from phantom_vlb_amd.datamodule import VLBDataModule, VLBDataModuleConfig
+    return VLBDataModule(VLBDataModuleConfig(lazyload_path="synthetic:3x4", subject="sub-01", seasons=["s1"], delay=3, window=3,
+                                             random_state=1234, shuffle_val_data=False, batch_size=batch_size, geometry="mini",
+                                             num_target=128))
+
+
+def test_checkpoint_resume_through_trainer_fit_is_exact(dev, tmp_path):
+    """6 steps in one run  ==  4 steps, checkpoint, and `Trainer.fit(ckpt_path=...)` in a fresh process-state for
+    steps 5-6 - with LoRA dropout 0.1 AND head dropout 0.1 active: the LR schedule, the counter-based dropout
+    seeds, the Adam moments and the clip order all continue (bit-exact masters and bf16 copies)."""
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.trainer import TrainableCheckpoint, Trainer
+    kw = dict(use_lora=True, freeze_backbone=False, lora_r=16, lora_alpha=32, lora_dropout=0.1, dropout_rate=0.1)
+    a = VLBLitModule(_cfg(**kw))
+    ta = Trainer(max_epochs=2, max_steps=6, val_check_interval=1.0, log_every_n_steps=1,
+                 callbacks=[TrainableCheckpoint(str(tmp_path), filename="best")])
+    ta.fit(a, _dm())
+    assert ta.global_step == 6
+    st = torch.load(tmp_path / "last.ckpt", map_location="cpu", weights_only=False)
+    assert st["global_step"] == 4 and st["lr_scheduler"]["last_epoch"] == 4 and st["rng"] == {"head_step": 4, "lora_step": 4}
+    assert st["state_dict"]["model.layers.0.self_attn.q_proj.lora_B.weight"].shape == (a.geometry.heads * a.geometry.head_dim, 16)
+    b = VLBLitModule(_cfg(**kw))
+    tb = Trainer(max_epochs=2, max_steps=6, val_check_interval=1.0, log_every_n_steps=1)
+    tb.fit(b, _dm(), ckpt_path=str(tmp_path / "last.ckpt"))
+    assert tb.global_step == 6 and b.optimizer.step_count == 6
+    assert b.optimizer.param_groups[0]["lr"] == a.optimizer.param_groups[0]["lr"]
+    assert torch.equal(a.flat.master, b.flat.master)
+    assert torch.equal(a.flat.compute, b.flat.compute)
+    # trainer.save_checkpoint(config.output_dir) (reference train.py:58): a directory gets final.ckpt
+    out = tb.save_checkpoint(str(tmp_path))
+    assert out.endswith("final.ckpt") and os.path.exists(out)
+
+
+def test_trainable_state_dict_round_trips_through_configure_model(dev):
+    """checkpoint `state_dict` (peft layout) merged into the backbone's state dict -> a fresh configure_model
+    reproduces masters, bf16 copies and predictions; rank 8 < 16 keeps its [8,in] / [out,8] shapes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vlb_oracle as O
     from phantom_vlb_amd.litmodule import VLBLitModule
     from phantom_vlb_amd.synthetic import synthetic_batch
-    from phantom_vlb_amd.trainer import TrainableCheckpoint, load_trainable_checkpoint
-
-    def fresh():
-        m = VLBLitModule(_cfg(use_lora=True, freeze_backbone=False, lora_r=16, lora_alpha=32, lora_dropout=0.0))
-        m.configure_model()
-        o, s = m.configure_optimizers()
-        return m, o[0], s[0]["scheduler"]
-    m, opt, sch = fresh()
-    batch = synthetic_batch(m.geometry, 2, seed=5, device=m.device)
-    for _ in range(3):
-        m.training_step(batch); opt.step(); sch.step()
-    ck = TrainableCheckpoint(str(tmp_path))
-    ck.save(m, str(tmp_path / "a.ckpt"), 3)
-    for _ in range(2):
-        m.training_step(batch); opt.step(); sch.step()
-    m2, opt2, sch2 = fresh()
-    assert load_trainable_checkpoint(m2, str(tmp_path / "a.ckpt")) == 3
-    for _ in range(3):
-        sch2.step()
-    for _ in range(2):
-        m2.training_step(batch); opt2.step(); sch2.step()
-    assert torch.equal(m.flat.master, m2.flat.master)
-    assert torch.equal(m.flat.compute, m2.flat.compute)
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=5))
+    for r in (16, 8):
+        kw = dict(use_lora=True, freeze_backbone=False, lora_r=r, lora_alpha=32, lora_dropout=0.0)
+        a = VLBLitModule(_cfg(**kw))
+        a.configure_model(state_dict=p, head_state=p)
+        opt, _ = a.configure_optimizers()
+        batch = synthetic_batch(a.geometry, 2, seed=5, device=a.device)
+        for _ in range(2):
+            a.training_step(batch); opt[0].step()
+        sd = a.trainable_state_dict()
+        assert sd["model.layers.1.mlp.down_proj.lora_A.weight"].shape == (r, g.ff)
+        assert sd["model.layers.1.mlp.down_proj.lora_B.weight"].shape == (g.dim, r)
+        assert float(sd["model.layers.1.mlp.down_proj.lora_B.weight"].abs().max()) > 0          # B has trained away from 0
+        b = VLBLitModule(_cfg(**kw))
+        b.configure_model(state_dict={**p, **sd})
+        b.configure_optimizers()
+        assert torch.equal(a.flat.master, b.flat.master) and torch.equal(a.flat.compute, b.flat.compute)
+        assert torch.equal(a.validation_step(batch)["brain_preds"], b.validation_step(batch)["brain_preds"])
+        if r < 16:            # padded adapter rows never leave zero
+            assert float(a.lora.master["model.layers.0.self_attn.q_proj.lora_A.weight"][r:].abs().max()) == 0.0
+            assert float(a.lora.master["model.layers.0.self_attn.q_proj.lora_B.weight"][r:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("lora", [False, True])

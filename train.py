@@ -1,9 +1,10 @@
 """Drop-in for the reference's train.py (train.py:1-70): same CLI
 ``python train.py experiment=<name> subject=<sub-XX>`` and the same YAML keys.
 
-Runs with real Hydra + Lightning when both are importable; otherwise uses the built-in config
-loader and fit loop (phantom_vlb_amd.config / phantom_vlb_amd.trainer).  Comet logging is optional:
-without ``comet_ml`` or credentials only the CSV logger is attached.
+The YAML is read by the built-in Hydra-subset loader (phantom_vlb_amd.config) and ``_target_:
+lightning.pytorch.Trainer`` is always routed to the built-in fit loop (phantom_vlb_amd.trainer) - also when
+Lightning is installed, because the module's backward pass is explicit.  Comet logging is
+optional: without ``comet_ml`` or credentials only the CSV logger is attached.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ sys.path.insert(0, ROOT)
 def train(config: dict) -> None:
     import torch
     from phantom_vlb_amd.config import instantiate
-    from phantom_vlb_amd.trainer import TrainableCheckpoint
+    from phantom_vlb_amd.trainer import LearningRateMonitor, TrainableCheckpoint
     from src import LogValAccuracyCallback
 
     seed = int(config.get("random_state", 1234))
@@ -30,6 +31,7 @@ def train(config: dict) -> None:
     callbacks = [
         TrainableCheckpoint(monitor="val/brain_loss", filename="best_brainloss", mode="min",
                             dirpath=config["output_dir"], save_last=True),
+        LearningRateMonitor(logging_interval="epoch"),
         LogValAccuracyCallback(),
     ]
     loggers = []
@@ -46,7 +48,7 @@ def train(config: dict) -> None:
     print("[train] datasets:", datamodule.datasets.dset_names)
     litmodule = instantiate(config["litmodule"])
     trainer.fit(model=litmodule, datamodule=datamodule)
-    callbacks[0].save(litmodule, os.path.join(config["output_dir"], "final.ckpt"), trainer.global_step)
+    trainer.save_checkpoint(config["output_dir"])          # reference train.py:58 -> <output_dir>/final.ckpt
 
 
 if __name__ == "__main__":
