@@ -10,7 +10,10 @@ What it pins (and how):
   3. Mistral decoder              vs installed transformers MistralModel (inputs_embeds + padding
      mask, eager attention, hidden_states[-1]).
   4. connector / splice / LoRA / mask layout have no importable reference: UNPINNED
-     (hand-checked known-answer vectors only).
+     (hand-checked known-answer vectors only; tests/test_cpu_pins.py adds independent in-container
+     cross-checks: LoRA vs autograd on the merged weight, connector vs torch.nn modules, splice vs a loop).
+The pins run as tests (tests/test_cpu_pins.py) whenever /root/reference and transformers are present, and the
+same file checks that the committed fixtures equal a fresh generation - oracle and goldens cannot drift apart.
 The reference itself never travels: only the numbers written here do.
 """
 from __future__ import annotations
@@ -145,52 +148,62 @@ def weights_digest(p):
     return h.hexdigest()
 
 
+def build_mask_kat():
+    cases = mask_known_answers()
+    return {f"{i}_{k}": v for i, c in enumerate(cases) for k, v in c.items()}
+
+
+def build_golden(tag: str) -> dict:
+    """The arrays of tests/golden/mini_<tag>.npz ('frozen' | 'lora'), regenerated from seeds (configs[0])."""
+    g = O.geometry_mini()
+    lora = tag == "lora"
+    p = O.round_bf16(O.init_params(g, seed=1234, lora=lora, lora_b_std=0.02 if lora else 0.0))
+    batch = O.synthetic_batch(g, batch=4, seed=1234)
+    names = O.trainable_names(p, freeze_backbone=not lora, use_lora=lora)
+    for n in names:
+        p[n].requires_grad_(True)
+    stages = {}
+    loss, pred = O.training_loss(p, batch, g, stages=stages)
+    loss.backward()
+    out = dict(
+        weights_sha256=np.array(weights_digest({k: v.detach() for k, v in p.items()})),
+        language=batch["language"].numpy(), padvals=batch["padvals"].numpy(),
+        vis_weights=batch["vis_weights"].numpy(), lang_weights=batch["lang_weights"].numpy(),
+        timeseries=batch["timeseries"].numpy(),
+        vision_probe=batch["vision"][:, 0, 0, :4, :4].numpy(),
+        weight_mask=stages["weight_mask"].numpy(),
+        vit_tokens=stages["vit_tokens"].detach().numpy().astype(np.float32),
+        video_tokens=stages["video_tokens"].detach().numpy(),
+        inputs_embeds_probe=stages["inputs_embeds"].detach()[:, ::7, ::5].numpy(),
+        key_mask=stages["key_mask"].numpy(),
+        layer0=stages["layer_outputs"][0].detach().numpy(),
+        hidden=stages["hidden"].detach().numpy(),
+        head_pooled=stages["head_pooled"].detach().numpy(),
+        head_ln2=stages["head_ln2"].detach().numpy(),
+        pred=pred.detach().numpy(), l2=stages["l2"].detach().numpy(), loss=loss.detach().numpy(),
+    )
+    for n in names:
+        if ".lora_" in n and not (n.startswith("model.layers.0.") or n.startswith(f"model.layers.{g.layers - 1}.")):
+            continue
+        out["grad::" + n] = p[n].grad.numpy()
+    out["grad_global_norm"] = np.array(float(torch.sqrt(sum(p[n].grad.double().pow(2).sum() for n in names))))
+    return out
+
+
 def main():
     torch.set_num_threads(8)
     pin_head()
     g = O.geometry_mini()
     pin_clip(g)
     pin_mistral(g)
-    cases = mask_known_answers()
     os.makedirs(GOLDEN, exist_ok=True)
-    np.savez_compressed(os.path.join(GOLDEN, "weight_mask_kat.npz"),
-                        **{f"{i}_{k}": v for i, c in enumerate(cases) for k, v in c.items()})
-
+    np.savez_compressed(os.path.join(GOLDEN, "weight_mask_kat.npz"), **build_mask_kat())
     # ---- mini config end-to-end golden (configs[0]): frozen backbone and LoRA variants
-    for tag, lora in (("frozen", False), ("lora", True)):
-        p = O.round_bf16(O.init_params(g, seed=1234, lora=lora, lora_b_std=0.02 if lora else 0.0))
-        batch = O.synthetic_batch(g, batch=4, seed=1234)
-        names = O.trainable_names(p, freeze_backbone=not lora, use_lora=lora)
-        for n in names:
-            p[n].requires_grad_(True)
-        stages = {}
-        loss, pred = O.training_loss(p, batch, g, stages=stages)
-        loss.backward()
-        out = dict(
-            weights_sha256=np.array(weights_digest({k: v.detach() for k, v in p.items()})),
-            language=batch["language"].numpy(), padvals=batch["padvals"].numpy(),
-            vis_weights=batch["vis_weights"].numpy(), lang_weights=batch["lang_weights"].numpy(),
-            timeseries=batch["timeseries"].numpy(),
-            vision_probe=batch["vision"][:, 0, 0, :4, :4].numpy(),
-            weight_mask=stages["weight_mask"].numpy(),
-            vit_tokens=stages["vit_tokens"].detach().numpy().astype(np.float32),
-            video_tokens=stages["video_tokens"].detach().numpy(),
-            inputs_embeds_probe=stages["inputs_embeds"].detach()[:, ::7, ::5].numpy(),
-            key_mask=stages["key_mask"].numpy(),
-            layer0=stages["layer_outputs"][0].detach().numpy(),
-            hidden=stages["hidden"].detach().numpy(),
-            head_pooled=stages["head_pooled"].detach().numpy(),
-            head_ln2=stages["head_ln2"].detach().numpy(),
-            pred=pred.detach().numpy(), l2=stages["l2"].detach().numpy(), loss=loss.detach().numpy(),
-        )
-        for n in names:
-            if ".lora_" in n and not (n.startswith("model.layers.0.") or n.startswith(f"model.layers.{g.layers - 1}.")):
-                continue
-            out["grad::" + n] = p[n].grad.numpy()
-        out["grad_global_norm"] = np.array(float(torch.sqrt(sum(p[n].grad.double().pow(2).sum() for n in names))))
+    for tag in ("frozen", "lora"):
+        out = build_golden(tag)
         path = os.path.join(GOLDEN, f"mini_{tag}.npz")
         np.savez_compressed(path, **out)
-        print(f"wrote {path}: loss={float(loss):.6f}  ({os.path.getsize(path) / 1e6:.2f} MB)")
+        print(f"wrote {path}: loss={float(out['loss']):.6f}  ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
 if __name__ == "__main__":

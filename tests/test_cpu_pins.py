@@ -1,0 +1,217 @@
+"""CPU tier: the oracle's pins as tests, the committed goldens against a fresh generation, and independent
+in-container cross-checks for the rows no importable reference exists for (connector, splice, LoRA: "parity
+unpinned" - the upstream VideoLLaMA2 / timm / peft sources are absent).
+
+* head  == the reference's OWN src/utils.py layers   (needs /root/reference; skipped on the GPU box)
+* CLIP  == transformers.CLIPVisionModel, Mistral == transformers.MistralModel   (needs transformers)
+* tests/golden/*.npz == oracle/gen_golden.build_golden() today: the oracle and its fixtures cannot drift apart
+* LoRA forward / gradients == torch autograd on the explicitly merged weight W + s.B.A (and the dropout form)
+* connector stages == torch.nn modules (Conv2d / Conv3d / Linear / LayerNorm) loaded from the same state-dict names
+* splice == an index-by-index Python loop
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+have_reference = os.path.isfile("/root/reference/src/utils.py")
+try:
+    import transformers  # noqa: F401
+    have_transformers = True
+except Exception:  # pragma: no cover
+    have_transformers = False
+
+
+@pytest.mark.skipif(not have_reference, reason="the reference tree only exists in the build container")
+def test_pin_head_against_the_reference_layers():
+    import gen_golden
+    gen_golden.pin_head()
+
+
+@pytest.mark.skipif(not have_transformers, reason="transformers not importable")
+def test_pin_clip_tower_against_transformers():
+    import gen_golden
+    import vlb_oracle as O
+    gen_golden.pin_clip(O.geometry_mini())
+
+
+@pytest.mark.skipif(not have_transformers, reason="transformers not importable")
+def test_pin_mistral_decoder_against_transformers():
+    import gen_golden
+    import vlb_oracle as O
+    gen_golden.pin_mistral(O.geometry_mini())
+
+
+@pytest.mark.parametrize("tag", ["frozen", "lora"])
+def test_committed_goldens_equal_a_fresh_generation(tag):
+    import gen_golden
+    fresh = gen_golden.build_golden(tag)
+    gold = np.load(os.path.join(GOLD, f"mini_{tag}.npz"))
+    assert set(gold.files) == set(fresh)
+    for k in gold.files:
+        a, b = gold[k], np.asarray(fresh[k])
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype.kind in "iubSU":
+            assert np.array_equal(a, b), k
+        else:
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(a).max()))), k
+
+
+def test_committed_mask_vectors_equal_a_fresh_generation():
+    import gen_golden
+    fresh = gen_golden.build_mask_kat()
+    gold = np.load(os.path.join(GOLD, "weight_mask_kat.npz"))
+    assert set(gold.files) == set(fresh)
+    for k in gold.files:
+        assert np.array_equal(gold[k], fresh[k]), k
+
+
+# ------------------------------------------------------------------ LoRA (peft absent): merged-weight autograd
+@pytest.mark.parametrize("r,drop", [(16, False), (8, False), (16, True)])
+def test_lora_linear_equals_autograd_on_the_merged_weight(r, drop):
+    """y = x W^T + (alpha/r) B A x  ==  x (W + (alpha/r) B A)^T, values and every gradient.  With dropout the adapter
+    sees x*keep/(1-p) while the base path sees x: checked against the two-term expression differentiated by hand."""
+    import vlb_oracle as O
+    torch.manual_seed(0)
+    din, dout, M, alpha, p = 48, 40, 33, 32, 0.25
+    g = O.Geometry(lora_r=r, lora_alpha=alpha)
+    s = alpha / r
+    W, A, B = torch.randn(dout, din) * 0.2, torch.randn(r, din) * 0.3, torch.randn(dout, r) * 0.3
+    x, dy = torch.randn(M, din), torch.randn(M, dout)
+    keep = (torch.rand(M, din) >= p).float() / (1 - p) if drop else None
+    P = {"l.weight": W, "l.lora_A.weight": A.clone().requires_grad_(True), "l.lora_B.weight": B.clone().requires_grad_(True)}
+    xo = x.clone().requires_grad_(True)
+    y = O._lin(P, "l", xo, g, lora_drop=None if keep is None else {"l": keep})
+    (y * dy).sum().backward()
+    if not drop:
+        Am, Bm, xm = A.clone().requires_grad_(True), B.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ym = F.linear(xm, W + s * Bm @ Am)
+        (ym * dy).sum().backward()
+        assert torch.allclose(y, ym, atol=1e-5)
+        assert torch.allclose(xo.grad, xm.grad, atol=1e-5)
+        assert torch.allclose(P["l.lora_A.weight"].grad, Am.grad, atol=1e-4)
+        assert torch.allclose(P["l.lora_B.weight"].grad, Bm.grad, atol=1e-4)
+    else:
+        xd = x * keep
+        assert torch.allclose(y, x @ W.t() + s * (xd @ A.t()) @ B.t(), atol=1e-5)
+        u = s * dy @ B                                  # [M, r]
+        assert torch.allclose(P["l.lora_B.weight"].grad, s * dy.t() @ (xd @ A.t()), atol=1e-4)
+        assert torch.allclose(P["l.lora_A.weight"].grad, u.t() @ xd, atol=1e-4)
+        assert torch.allclose(xo.grad, dy @ W + keep * (u @ A), atol=1e-5)
+
+
+# ------------------------------------------------------------------ connector (timm / VideoLLaMA2 absent): nn modules
+class _LayerNorm2d(nn.LayerNorm):
+    def forward(self, x):
+        return super().forward(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class _ConvNormAct(nn.Module):
+    def __init__(self, cin, cout, k, groups=1, act=True, eps=1e-6):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=k // 2, groups=groups, bias=False)
+        self.bn = _LayerNorm2d(cout, eps=eps)
+        self.act = nn.SiLU() if act else nn.Identity()
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+
+class _SE(nn.Module):
+    def __init__(self, c, rd):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Conv2d(c, rd, 1), nn.Conv2d(rd, c, 1)
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.fc2(F.silu(self.fc1(x.mean((2, 3), keepdim=True)))))
+
+
+class _Bottleneck(nn.Module):
+    """RegNet bottleneck as the published timm architecture describes it (bottle_ratio 1, group width 1 -> depthwise
+    3x3, SE on the bottleneck width with rd = round(in_chs * 0.25), LayerNorm2d norms, SiLU; conv1x1 shortcut on a
+    channel change) - built from stock torch.nn modules, attribute names = the state-dict names."""
+
+    def __init__(self, cin, cout, se_ratio, eps):
+        super().__init__()
+        self.conv1 = _ConvNormAct(cin, cout, 1, eps=eps)
+        self.conv2 = _ConvNormAct(cout, cout, 3, groups=cout, eps=eps)
+        self.se = _SE(cout, int(round(cin * se_ratio)))
+        self.conv3 = _ConvNormAct(cout, cout, 1, act=False, eps=eps)
+        self.downsample = _ConvNormAct(cin, cout, 1, act=False, eps=eps) if cin != cout else None
+
+    def forward(self, x):
+        sc = x if self.downsample is None else self.downsample(x)
+        return F.silu(self.conv3(self.se(self.conv2(self.conv1(x)))) + sc)
+
+
+class _STC(nn.Module):
+    def __init__(self, g):
+        super().__init__()
+        def stage(cin):
+            return nn.ModuleDict({f"b{i + 1}": _Bottleneck(cin if i == 0 else g.dim, g.dim, g.proj_se_ratio, g.proj_eps)
+                                  for i in range(g.proj_depth)})
+        self.s1, self.s2 = stage(g.vit_dim), stage(g.dim)
+        self.sampler = nn.Sequential(nn.Conv3d(g.dim, g.dim, 2, stride=2, padding=1), nn.SiLU())
+        self.readout = nn.Sequential(nn.Linear(g.dim, g.dim), nn.GELU(), nn.Linear(g.dim, g.dim))
+
+    def forward(self, feats, g):
+        B, T = feats.shape[:2]
+        x = feats.reshape(B * T, g.grid, g.grid, g.vit_dim).permute(0, 3, 1, 2)
+        for blk in self.s1.values():
+            x = blk(x)
+        x = self.sampler(x.reshape(B, T, g.dim, g.grid, g.grid).transpose(1, 2))           # b d t h w
+        nt, nh = x.shape[2], x.shape[3]
+        x = x.transpose(1, 2).reshape(B * nt, g.dim, nh, nh)
+        for blk in self.s2.values():
+            x = blk(x)
+        x = x.reshape(B, nt, g.dim, nh * nh).permute(0, 1, 3, 2).reshape(B, nt * nh * nh, g.dim)
+        return self.readout(x)
+
+
+def test_stc_connector_equals_torch_nn_modules_with_the_same_state_dict():
+    import vlb_oracle as O
+    g = O.geometry_mini()
+    p = O.init_params(g, seed=11)
+    pre = "model.mm_projector."
+    sd = {k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}
+    net = _STC(g)
+    missing, unexpected = net.load_state_dict(sd, strict=True)          # every oracle tensor has a home, and vice versa
+    assert not missing and not unexpected
+    torch.manual_seed(3)
+    feats = torch.randn(2, g.num_frames, g.grid * g.grid, g.vit_dim)
+    with torch.no_grad():
+        ref = net(feats, g)
+        got = O.stc_connector(p, feats, g)
+    assert ref.shape == got.shape == (2, g.vis_tokens, g.dim)
+    assert torch.allclose(ref, got, atol=1e-5), float((ref - got).abs().max())
+
+
+def test_splice_equals_an_index_by_index_loop():
+    import vlb_oracle as O
+    g = O.geometry_mini()
+    torch.manual_seed(5)
+    batch = O.synthetic_batch(g, 3, seed=9)
+    ids = batch["language"].long()
+    E = torch.randn(g.vocab, 8)
+    vid = torch.randn(3, g.vis_tokens, 8)
+    emb, mask = O.splice_multimodal(E, ids, vid)
+    assert emb.shape == (3, g.max_len, 8) and mask.shape == (3, g.max_len)
+    for b in range(3):
+        out_row, out_mask = [], []
+        for t in ids[b].tolist():
+            if t == O.VIDEO_TOKEN_ID:
+                out_row += [vid[b, j] for j in range(g.vis_tokens)]
+                out_mask += [True] * g.vis_tokens
+            else:
+                out_row.append(E[t])
+                out_mask.append(t != 0)
+        assert torch.equal(emb[b], torch.stack(out_row))
+        assert mask[b].tolist() == out_mask
