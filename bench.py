@@ -168,7 +168,11 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    from phantom_vlb_amd import ops
+    from phantom_vlb_amd import _lib, ops
+    if not _lib.IS_PRODUCT_LIB:
+        print(f"bench.py: refusing to benchmark {_lib.LIB_PATH} (VLB_LIB is set): only the in-tree product library "
+              "phantom_vlb_amd/libvlb.so is measured", file=sys.stderr)
+        sys.exit(2)
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
 

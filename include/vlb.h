@@ -16,7 +16,11 @@
  *   - Return 0 on success, negative VLB_ERR_* otherwise; vlb_last_error() gives a
  *     thread-local message.  Nothing throws or aborts across the boundary.
  *   - "bf16" buffers are raw 16-bit bfloat16; row-major; `ld*` are row strides in ELEMENTS.
- *   - Functions are stateless and re-entrant; one process per GPU.
+ *   - Functions are re-entrant and may be called from several host threads: the only process state is the
+ *     one-time LDS-size attribute of a few kernels, set through thread-safe static initialisation on first use
+ *     (it applies to the current device: one process per GPU).  The exported symbols are exactly the functions
+ *     declared here - kernel-variant switches and timing-only ablations exist only in the separate tools build
+ *     (libvlb_tools.so, `make -C phantom_vlb_amd/csrc tools`), which the package, bench.py and tests never load.
  */
 #ifndef VLB_H
 #define VLB_H

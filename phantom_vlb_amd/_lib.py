@@ -15,7 +15,10 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlb.so")
+# VLB_LIB: tools/*.py point this at libvlb_tools.so (the -DVLB_TOOLS build with kernel-variant switches and
+# timing-only ablations) for A/B runs.  bench.py and the tests refuse anything but the in-tree product library.
+LIB_PATH = os.environ.get("VLB_LIB") or os.path.join(_HERE, "libvlb.so")
+IS_PRODUCT_LIB = os.path.abspath(LIB_PATH) == os.path.join(_HERE, "libvlb.so")
 
 P, I, F, L = c_void_p, c_int, c_float, c_int64
 

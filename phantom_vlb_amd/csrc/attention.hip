@@ -275,13 +275,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 template <int D, bool CAUSAL>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * 2 * KV * D * 2;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, CAUSAL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { vlb_set_error("attention: LDS reservation failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
-    configured = true;
-  }
+  // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, CAUSAL>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) { vlb_set_error("attention: LDS reservation failed: %s", hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
   dim3 grid(((a.S + QB - 1) / QB) * a.Hq * a.B);
   hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), grid, dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
@@ -319,9 +316,16 @@ namespace {
 constexpr int BK_KEYS = 128;   // keys per workgroup
 constexpr int BQ = 32;         // queries per inner block
 
+// The product library runs ONE backward: per-q-head dK/dV workgroups + GQA reduce + dQ pass.  The superseded 8-wave
+// per-kv-head kernel (with or without fp32 dQ atomics) and its timing-only ablations exist only in the tools build
+// (libvlb_tools.so, -DVLB_TOOLS) for tools/bench_attention.py's A/B.
+#ifdef VLB_TOOLS
 int g_attn_ablate = 0;
 int g_attn_split_dq = 1;      // 1 (default): per-q-head dK/dV workgroups + dQ pass; 2: the 8-wave per-kv-head dK/dV kernel + dQ pass;
                               // 0: 8-wave kernel with fp32 dQ atomics (A/B only)
+#else
+constexpr int g_attn_ablate = 0, g_attn_split_dq = 1;
+#endif
 struct AttnBwdArgs {
   const bf16* q; const bf16* k; const bf16* v; const bf16* dout;
   const float* lse; const float* delta; const uint8_t* mask; const int* cu;
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
   }
 }
 
+#ifdef VLB_TOOLS
 // 8 waves per workgroup: waves 0-3 and 4-7 ("groups") own the SAME 4 x 32 keys but sweep different
 // q-heads of the GQA group, so every SIMD holds two waves whose MFMA / LDS / VALU / atomic phases
 // overlap; K and V tiles are shared, Q/dO/dS^T/lse buffers are per group, and the two partial
@@ -627,6 +632,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(AttnBwdArgs p) {
       }
   }
 }
+
+#endif  // VLB_TOOLS (superseded 8-wave dK/dV kernel)
 
 // -------------------------------------------------------------------------------------------------
 // dK / dV pass, one workgroup per (128 keys, q-head).  The causal triangle gives the first key block 16x the work
@@ -1019,6 +1026,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnDqArgs p) {
   }
 }
 
+#ifdef VLB_TOOLS
 // dq (bf16, strided) = dq_acc (fp32 [B*S, Hq*128])
 __global__ void dq_convert_kernel(const float* __restrict__ acc, bf16* __restrict__ dq, int lddq, int width, int64_t total) {
   const int cpr = width >> 3;
@@ -1032,6 +1040,7 @@ __global__ void dq_convert_kernel(const float* __restrict__ acc, bf16* __restric
     *reinterpret_cast<bf16x8*>(dq + row * lddq + c) = o;
   }
 }
+#endif
 }  // namespace
 
 extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out,
@@ -1040,7 +1049,7 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
                                  int S, int Hq, int Hkv, int D, int causal, float scale, const int* cu_rows, int total_rows,
                                  void* stream) {
   VLB_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta, "attention_bwd: null operand");
-  VLB_REQUIRE(dq_acc || g_attn_split_dq == 2 || (g_attn_split_dq == 1 && Hq == Hkv), "attention_bwd: the fp32 [rows, Hq, D] workspace is required");
+  VLB_REQUIRE(dq_acc || g_attn_split_dq == 2 || (g_attn_split_dq == 1 && Hq == Hkv), "attention_bwd: the [rows, Hq, D] fp32-sized workspace is required");
   VLB_REQUIRE(D == 128, "attention_bwd: head dim %d unsupported (only 128: the decoder)", D);
   VLB_REQUIRE(B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_bwd: bad shape");
   VLB_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 &&
@@ -1052,34 +1061,41 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((th + 15) / 16)), dim3(256), 0, st, (const bf16*)out, ldo,
                      (const bf16*)dout, lddo, delta, S, Hq, B, cu_rows, th);
   VLB_LAUNCH_CHECK();
-  const int split = g_attn_split_dq;
-  if (!split) {
-    hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
-    if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
-  }
   AttnBwdArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
-                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale, g_attn_ablate, split};
-  constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed"); return VLB_ERR_LAUNCH; }
-    configured = true;
-  }
+                (bf16*)dk, (bf16*)dv, dq_acc, ldq, ldk, ldv, lddo, lddk, lddv, B, S, Hq, Hkv, scale, g_attn_ablate, g_attn_split_dq};
   dim3 grid((S + BK_KEYS - 1) / BK_KEYS, Hkv, B);
-  if (split == 1) {
+#ifdef VLB_TOOLS
+  if (g_attn_split_dq != 1) {        // superseded 8-wave per-kv-head kernel (A/B only)
+    const int split = g_attn_split_dq;
+    if (!split) {
+      hipError_t e = hipMemsetAsync(dq_acc, 0, (size_t)th * D * sizeof(float), st);
+      if (e != hipSuccess) { vlb_set_error("attention_bwd: memset failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+    }
+    constexpr int LDS = 2 * BK_KEYS * 256 + 2 * (4 * BQ * 256 + BK_KEYS * 64 + 512);   // 145 KB
+    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (a1 != hipSuccess || a2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed"); return VLB_ERR_LAUNCH; }
+    if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
+    VLB_LAUNCH_CHECK();
+    if (!split) {
+      const int64_t total = rows * (Hq * D / 8);
+      int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(dq_convert_kernel, dim3(blocks), dim3(256), 0, st, dq_acc, (bf16*)dq, lddq, Hq * D, total);
+      VLB_LAUNCH_CHECK();
+      return VLB_OK;
+    }
+  } else
+#endif
+  {
     const int gsz = Hq / Hkv;
     VLB_REQUIRE(gsz == 1 || dq_acc, "attention_bwd: the workspace (fp32 [rows, Hq, D]) is required for grouped-query heads");
     VLB_REQUIRE(lddk % 8 == 0 && lddv % 8 == 0 && (((uintptr_t)dk | (uintptr_t)dv) % 16) == 0, "attention_bwd: dk/dv rows must be 16-byte aligned");
     constexpr int LDS_KV = BK_KEYS * 256 + 4 * BQ * 256 + 512;        // 65 KB: two workgroups per CU
-    static bool configured_kv = false;
-    if (!configured_kv) {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
-      if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dk/dv)"); return VLB_ERR_LAUNCH; }
-      configured_kv = true;
-    }
+    // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
+    static const hipError_t k1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+    static const hipError_t k2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+    if (k1 != hipSuccess || k2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dk/dv)"); return VLB_ERR_LAUNCH; }
     bf16* part = reinterpret_cast<bf16*>(dq_acc);        // rows*Hq*256 bf16 = the same bytes as fp32 [rows, Hq, 128]
     dim3 gridh(grid.x * Hq * B);                         // 1-D, heaviest key blocks first (see the kernel)
     if (causal) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, gridh, dim3(256), LDS_KV, st, a, part);
@@ -1089,35 +1105,23 @@ extern "C" int vlb_attention_bwd(const void* q, int ldq, const void* k, int ldk,
       const int64_t tot = rows * Hkv * 32;
       hipLaunchKernelGGL(attn_dkdv_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part, (bf16*)dk, lddk,
                          (bf16*)dv, lddv, Hq, Hkv, tot);
+      VLB_LAUNCH_CHECK();
     }
-  } else {
-    if (causal) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(512), LDS, st, a);
-    else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(512), LDS, st, a);
   }
-  VLB_LAUNCH_CHECK();
-  if (split) {
-    AttnDqArgs d{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
-                 (bf16*)dq, ldq, ldk, ldv, lddo, lddq, B, S, Hq, Hkv, scale};
-    constexpr int LDS_DQ = 2 * 2 * KV * 256;       // 64 KB: two workgroups per CU
-    static bool configured_dq = false;
-    if (!configured_dq) {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-      if (e1 != hipSuccess || e2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dq)"); return VLB_ERR_LAUNCH; }
-      configured_dq = true;
-    }
-    dim3 gq(((S + QB - 1) / QB) * Hq * B);
-    if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), LDS_DQ, st, d);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), LDS_DQ, st, d);
-    VLB_LAUNCH_CHECK();
-    return VLB_OK;
-  }
-  const int64_t total = rows * (Hq * D / 8);
-  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dq_convert_kernel, dim3(blocks), dim3(256), 0, st, dq_acc, (bf16*)dq, lddq, Hq * D, total);
+  AttnDqArgs d{(const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)dout, lse, delta, key_mask, cu_rows,
+               (bf16*)dq, ldq, ldk, ldv, lddo, lddq, B, S, Hq, Hkv, scale};
+  constexpr int LDS_DQ = 2 * 2 * KV * 256;       // 64 KB: two workgroups per CU
+  static const hipError_t q1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+  static const hipError_t q2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+  if (q1 != hipSuccess || q2 != hipSuccess) { vlb_set_error("attention_bwd: LDS reservation failed (dq)"); return VLB_ERR_LAUNCH; }
+  dim3 gq(((S + QB - 1) / QB) * Hq * B);
+  if (causal) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(256), LDS_DQ, st, d);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(256), LDS_DQ, st, d);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
 
+#ifdef VLB_TOOLS
 // tuning hook (not part of the stable ABI): timing-only ablations of the attention backward kernel
 extern "C" void vlb_attn_set_ablation(int bits) { g_attn_ablate = bits & 3; g_attn_split_dq = (bits & 4) ? 0 : ((bits & 8) ? 2 : 1); }   // bit2: atomic dQ; bit3: 8-wave dK/dV + dQ pass
+#endif

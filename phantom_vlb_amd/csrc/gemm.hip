@@ -859,15 +859,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
 template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
+  // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-      return VLB_ERR_LAUNCH;
-    }
-    configured = true;
+  if (attr != hipSuccess) {
+    vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return VLB_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
@@ -887,12 +884,21 @@ int launch_w4_splitk(GemmArgs& a, hipStream_t s) {
   return VLB_OK;
 }
 
-int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong wave groups, 2: four-wave 128x128 blocks,
-                        // 3 (default): four-wave kernel for long K (>= 4096), ping-pong otherwise, 192-row tiles
-                        // when the cost model prefers them; 5 (A/B): like 3 but always 192-row tiles for long K
-int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
-int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
-int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
+// Kernel selection.  The product library (libvlb.so) is built WITHOUT VLB_TOOLS: the selection below is a
+// compile-time constant, no ablation / superseded kernel is instantiated and no switch is exported.
+// `make tools` builds libvlb_tools.so with -DVLB_TOOLS for tools/bench_gemm_variants.py & co (A/B and timing-only
+// ablations whose results are wrong by construction); nothing under phantom_vlb_amd/, bench.py or tests/ loads it.
+#ifdef VLB_TOOLS
+#define VLB_TUNABLE
+#else
+#define VLB_TUNABLE constexpr
+#endif
+VLB_TUNABLE int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong wave groups, 2: four-wave 128x128 blocks,
+                                    // 3 (default): four-wave kernel for long K (>= 4096), ping-pong otherwise, 192-row tiles
+                                    // when the cost model prefers them; 5 (A/B): like 3 but always 192-row tiles for long K
+VLB_TUNABLE int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
+VLB_TUNABLE int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
+VLB_TUNABLE int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
 
 // How the partial last wave of `tiles` tiles (nk K-tiles each) is run.  Costs are in units of one full wave of
 // tiles: whole tiles 1.0; re-cut 256x128 halves 0.62 (measured 0.6-0.8); split-K 1/s plus ~16 K-tiles' worth
@@ -923,15 +929,12 @@ inline bool plan_rows(int M, int N, int Ktot, bool ws_ok, TailPlan& p256, TailPl
 
 template <int BM, int BN, int WM, int WN, int S0, int S1, int S2, int S3, int ABL = 0>
 int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>),
+  // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
-      return VLB_ERR_LAUNCH;
-    }
-    configured = true;
+  if (attr != hipSuccess) {
+    vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(attr));
+    return VLB_ERR_LAUNCH;
   }
   hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, WM, WN, S0, S1, S2, S3, ABL>), dim3(a.grid), dim3(512), lds, s, a);
   VLB_LAUNCH_CHECK();
@@ -941,16 +944,14 @@ int launch_pp(GemmArgs& a, hipStream_t s, int lds) {
 template <int BM, int BN, int WM, int WN>
 int launch_tile(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<BM, BN, WM, WN>),
+#ifdef VLB_TOOLS      // the lock-step kernel (variant 0) only exists in the tools build
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<BM, BN, WM, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-      return VLB_ERR_LAUNCH;
-    }
-    configured = true;
+  if (attr != hipSuccess) {
+    vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return VLB_ERR_LAUNCH;
   }
+#endif
   if (a.grid == 0) {          // plain launch: the whole GEMM with BM x BN tiles
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = a.N / BN;
@@ -960,11 +961,19 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
   // the 4-wave kernel addresses operands with 32-bit byte offsets
   const bool fits32 = (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31) &&
                       (int64_t)a.M * a.lda2 < (1ll << 31) && (int64_t)a.N * a.ldw2 < (1ll << 31);
+#ifndef VLB_TOOLS
+  // the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and epilogue (one
+  // workgroup per CU, nothing to overlap them with): measured crossover K ~ 3072-4096
+  if constexpr (BM == 256 && BN == 256) {
+    if (fits32 && a.K + a.K2 >= 4096) return launch_w4<8, 0>(a, s);
+  } else if constexpr (BM == 256 && BN == 128) {
+    if (fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
+  }
+  return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+#else
   if constexpr (BM == 256 && BN == 256) {
     if (!fits32 && (g_variant == 2 || (g_variant >= 0x20 && g_variant < 0x30))) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
     if (g_variant == 2) return launch_w4<8, 0>(a, s);
-    // auto: the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and
-    // epilogue (one workgroup per CU, nothing to overlap them with): measured crossover K ~ 3072-4096
     if (g_variant == 3 || g_variant == 4 || g_variant == 5) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
       if (fits32 && a.K + a.K2 >= 4096) return launch_w4<8, 0>(a, s);
       return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
@@ -1000,6 +1009,7 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WM, WN>), dim3(a.grid), dim3(512), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
+#endif
 }
 
 // 16x16 LDS-tiled transpose, 32x32 elements per block
@@ -1233,13 +1243,15 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   return use192 ? launch_w4<4, 0, 6, true>(lo, s) : launch_w4<4, 0, 8, true>(lo, s);
 }
 
-// tuning hooks (not part of the stable ABI): kernel variant / forced tile
+#ifdef VLB_TOOLS
+// tuning hooks, libvlb_tools.so only: kernel variant / forced tile
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;
   g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
   g_tail_splitk = (variant & 0x200) ? 0 : 1;   // bit 9 disables the split-K tail (A/B)
 }
+#endif
 
 extern "C" int vlb_transpose_bf16(const void* in, void* out, int R, int C, void* stream) {
   VLB_REQUIRE(in && out && R > 0 && C > 0, "transpose: bad args");

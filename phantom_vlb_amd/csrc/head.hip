@@ -559,13 +559,10 @@ template <int NI>
 int launch_pool(const bf16* hidden, const float* wmask, float* partial, float* stats, int B, int S, int E, float eps,
                 const int* cu, hipStream_t st) {
   const int lds = (4 * E + 8) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pool_kernel<NI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (4 * NI * 512 + 8) * (int)sizeof(float));
-    if (e != hipSuccess) { vlb_set_error("head: LDS reservation failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
-    configured = true;
-  }
+  // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pool_kernel<NI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (4 * NI * 512 + 8) * (int)sizeof(float));
+  if (attr != hipSuccess) { vlb_set_error("head: LDS reservation failed: %s", hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
   dim3 grid((S + POOL_ROWS - 1) / POOL_ROWS, B);
   hipLaunchKernelGGL((head_pool_kernel<NI>), grid, dim3(512), lds, st, hidden, wmask, partial, stats, S, E, eps, cu);
   VLB_LAUNCH_CHECK();

@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+os.environ.pop("VLB_LIB", None)      # the tests always exercise the in-tree product library, never the tools build
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -2,6 +2,8 @@
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _toolslib  # noqa: E402,F401  (libvlb_tools.so: variant switches / ablations live only there)
 from phantom_vlb_amd import ops
 from phantom_vlb_amd._lib import lib
 
