@@ -298,6 +298,30 @@ int vlb_adamw_step(float* master, void* param_bf16, const float* grad, float* m,
                    float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq,
                    float max_norm, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Exchange steps of the sharded training step over RCCL / xGMI - what an fsdp.yaml-driven run of the reference
+ * (fsdp.yaml:5-14 FULL_SHARD; never loaded by its mainline) would issue through torch FSDP's NCCL calls:
+ * parameter all-gather, gradient reduce-scatter, the clip norm's scalar all-reduce.  "direct" = all-pairs
+ * schedules: every shard crosses its own xGMI link (grouped ncclSend/ncclRecv), and the reduce-scatter sums the
+ * staged slices in RANK ORDER in one local kernel, so reduced gradients are bit-reproducible.
+ * RCCL (librccl.so.1) is bound with dlopen at first use; one communicator per process (= per GPU); calls enqueue on
+ * `stream` and return; the handle is created from a 128-byte unique id that rank 0 makes and the caller
+ * distributes (torch.distributed's store / a broadcast).  Buffers are caller-owned device memory.
+ */
+int vlb_comm_unique_id(void* id128_host);                                     /* host buffer of 128 bytes (rank 0) */
+int vlb_comm_init(int rank, int world, const void* id128_host, void** comm_out);
+int vlb_comm_destroy(void* comm);
+int vlb_comm_rank(void* comm);
+int vlb_comm_world(void* comm);
+/* full[r*shard_bytes ...] = rank r's shard, for every r.  In place when shard == full + rank*shard_bytes. */
+int vlb_allgather_direct(void* comm, const void* shard, void* full, int64_t shard_bytes, void* stream);
+/* out[n_per_rank] = sum over ranks r (in rank order) of rank r's send[rank*n_per_rank ...]; fp32; `stage` holds
+ * vlb_reducescatter_stage_floats(n_per_rank, world) floats; n_per_rank % 4 == 0, 16-byte aligned buffers. */
+int64_t vlb_reducescatter_stage_floats(int64_t n_per_rank, int world);
+int vlb_reducescatter_direct(void* comm, const float* send, float* out, int64_t n_per_rank, float* stage, void* stream);
+/* values[0..count) summed over ranks in place (the clip norm's sum of squares, logged losses) */
+int vlb_allreduce_scalar(void* comm, float* values, int count, void* stream);
+
 /* head dropout mask (litmodule :226,251 nn.Dropout(p) in training): out[i] = keep_i / (1-p), keep_i from a
  * counter-based hash of (seed, i) with 16 random bits per element (same mixer as the LoRA masks).  The result is
  * what vlb_head_fwd / vlb_head_bwd take as `keep_scale`. */

@@ -68,11 +68,20 @@ SIGNATURES = {
     "vlb_grad_sumsq": [P, L, P, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "vlb_dropout_keep_scale": [P, L, F, ctypes.c_uint32, P],
+    "vlb_comm_unique_id": [P],
+    "vlb_comm_init": [I, I, P, ctypes.POINTER(c_void_p)],
+    "vlb_comm_destroy": [P],
+    "vlb_comm_rank": [P],
+    "vlb_comm_world": [P],
+    "vlb_allgather_direct": [P, P, P, L, P],
+    "vlb_reducescatter_stage_floats": [L, I],
+    "vlb_reducescatter_direct": [P, P, P, L, P, P],
+    "vlb_allreduce_scalar": [P, P, I, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
 _RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
-             "vlb_gemm_workspace_bytes": c_int64}
+             "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64}
 
 
 class VlbError(RuntimeError):

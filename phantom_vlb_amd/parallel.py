@@ -121,7 +121,7 @@ class ShardedFlatState:
             off += (e - s) // w
         self.numel = off
         assert off * w == flat.numel
-        self.active = w > 1 or (force_collectives and dist.is_initialized())
+        self.active = w > 1 or (force_collectives and (dist.is_initialized() or not isinstance(self.comm, TorchComm)))
         if not self.active:
             self.master, self.compute, self.grad, self.m, self.v = flat.master, flat.compute, flat.grad, flat.m, flat.v
         else:
