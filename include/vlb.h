@@ -299,6 +299,46 @@ int vlb_adamw_step(float* master, void* param_bf16, const float* grad, float* m,
                    float max_norm, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Full-parameter fine-tuning (BASELINE configs[4]; litmodule :86-99 with freeze_backbone=False, use_lora=False:
+ * everything but the vision tower trains).  What torch autograd does for the reference behind loss.backward():
+ * weight gradients of every linear / 1x1 conv are the SAME TN GEMM (vlb_gemm_bf16) on transposed activations,
+ * dW[N,K] = dy^T[N,M] . (x^T[K,M])^T; the entries below are the HBM-bound pieces around it.  Gradients of backbone
+ * parameters are bf16 (the reference's parameters and therefore their autograd gradients are bf16, litmodule :155).
+ */
+/* out[C, ld_out] = in[R, C]^T with columns R..Rpad-1 written as zeros (token axis padded to the GEMM K granule) */
+int vlb_transpose_pad(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rpad, void* stream);
+/* workspace (floats) of the two norm backward entries below and of vlb_colsum */
+int64_t vlb_norm_bwd_ws_floats(int rows, int dim);
+int64_t vlb_colsum_ws_floats(int rows, int dim);
+/* RMSNorm weight gradient: dw[c] = sum_rows dy * x * rsqrt(mean(x^2)+eps)  (modeling_mistral.py:182-196 backward) */
+int vlb_rmsnorm_bwd_dw(const void* x, const void* dy, void* dw_bf16, float* ws, int rows, int dim, float eps, void* stream);
+/* backward of vlb_layernorm_fwd (y = act(LN(x; w, b) + residual)): dx, d residual (may be NULL), dw, db */
+int vlb_layernorm_bwd(const void* x, const void* w, const void* b, const void* residual, const void* dy, void* dx, void* dres,
+                      void* dw_bf16, void* db_bf16, float* ws, int rows, int dim, float eps, int act, void* stream);
+/* y = act(x): the training forward keeps pre-activations, so activations the inference path fuses into GEMM
+ * epilogues (sampler SiLU, readout GELU, SE SiLU) run as their own pass (n % 8 == 0) */
+int vlb_act_fwd(const void* x, void* y, int64_t n, int act, void* stream);
+/* dx = dy * act'(x) for VLB_ACT_SILU / VLB_ACT_GELU / VLB_ACT_QUICK_GELU (n % 8 == 0) */
+int vlb_act_bwd(const void* x, const void* dy, void* dx, int64_t n, int act, void* stream);
+/* bias gradients: out[c] = sum_r x[r, c] */
+int vlb_colsum(const void* x, int ld, void* out_bf16, float* ws, int rows, int dim, void* stream);
+/* embed_tokens gradient (splice backward): dE[tok[j]] = sum of d_embeds rows rows[beg[j] .. beg[j+1]) (host-built lists) */
+int vlb_embed_grad(const void* d_embeds, int ld, const int* tok, const int* beg, const int* rows, int n_tokens, void* dE, int D,
+                   void* stream);
+/* clip norm / AdamW on bf16 gradients (n % 8 == 0); same contract as vlb_grad_sumsq / vlb_adamw_step */
+int vlb_grad_sumsq_bf16(const void* g, int64_t n, float* sumsq, float* ws, void* stream);
+int vlb_adamw_step_g16(float* master, void* param_bf16, const void* grad_bf16, float* m, float* v, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq, float max_norm,
+                       void* stream);
+/* STC connector backward pieces: depthwise 3x3 weight gradient [9,C]; squeeze-excite gate-logit and input gradients;
+ * inverse of vlb_im2col3d_k2s2p1 (every input element sits in exactly one 2x2x2 window) */
+int64_t vlb_dwconv3x3_bwd_w_ws_floats(int N, int C);
+int vlb_dwconv3x3_bwd_w(const void* x, const void* dy, void* dw9_bf16, float* ws, int N, int H, int W, int C, void* stream);
+int vlb_se_bwd_gate(const void* x, const void* dy, const void* s, void* ds, int N, int HW, int C, void* stream);
+int vlb_se_bwd_x(const void* dy, const void* s, const void* dpool, void* dx, int N, int HW, int C, void* stream);
+int vlb_col2im3d_k2s2p1(const void* dcols, void* dx, int B, int T, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Exchange steps of the sharded training step over RCCL / xGMI - what an fsdp.yaml-driven run of the reference
  * (fsdp.yaml:5-14 FULL_SHARD; never loaded by its mainline) would issue through torch FSDP's NCCL calls:
  * parameter all-gather, gradient reduce-scatter, the clip norm's scalar all-reduce.  "direct" = all-pairs

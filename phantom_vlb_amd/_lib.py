@@ -68,6 +68,22 @@ SIGNATURES = {
     "vlb_grad_sumsq": [P, L, P, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "vlb_dropout_keep_scale": [P, L, F, ctypes.c_uint32, P],
+    "vlb_transpose_pad": [P, I, P, I, I, I, I, P],
+    "vlb_norm_bwd_ws_floats": [I, I],
+    "vlb_colsum_ws_floats": [I, I],
+    "vlb_rmsnorm_bwd_dw": [P, P, P, P, I, I, F, P],
+    "vlb_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, I, P],
+    "vlb_act_fwd": [P, P, L, I, P],
+    "vlb_act_bwd": [P, P, P, L, I, P],
+    "vlb_colsum": [P, I, P, P, I, I, P],
+    "vlb_embed_grad": [P, I, P, P, P, I, P, I, P],
+    "vlb_grad_sumsq_bf16": [P, L, P, P, P],
+    "vlb_adamw_step_g16": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
+    "vlb_dwconv3x3_bwd_w_ws_floats": [I, I],
+    "vlb_dwconv3x3_bwd_w": [P, P, P, P, I, I, I, I, P],
+    "vlb_se_bwd_gate": [P, P, P, P, I, I, I, P],
+    "vlb_se_bwd_x": [P, P, P, P, I, I, I, P],
+    "vlb_col2im3d_k2s2p1": [P, P, I, I, I, I, I, P],
     "vlb_comm_unique_id": [P],
     "vlb_comm_init": [I, I, P, ctypes.POINTER(c_void_p)],
     "vlb_comm_destroy": [P],
@@ -81,7 +97,8 @@ SIGNATURES = {
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
 _RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
-             "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64}
+             "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64,
+             "vlb_norm_bwd_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
 
 
 class VlbError(RuntimeError):

@@ -143,12 +143,8 @@ class VLBLitModule(_Base):
         if getattr(self, "nnmodule", None) is not None:
             return
         cfg = self.config
-        if not cfg.freeze_backbone and not cfg.use_lora:
-            # reference :96-111: everything but the vision tower trains.  The decoder / connector weight gradients
-            # and the 7B-wide optimiser state are not built (BASELINE configs[4]); never fall back silently to a
-            # frozen backbone.
-            raise NotImplementedError("full-parameter fine-tuning (freeze_backbone=False, use_lora=False) is not "
-                                      "implemented: use freeze_backbone=True (configs[1]) or use_lora=True (configs[2-3])")
+        # reference :86-111: freeze_backbone=False and use_lora=False -> everything but the vision tower trains
+        full_ft = not cfg.freeze_backbone and not cfg.use_lora
         g = self.geometry = resolve_geometry(cfg)
         dev = self.device
         torch.cuda.set_device(dev)
@@ -159,7 +155,7 @@ class VLBLitModule(_Base):
                 warnings.warn(f"model_path={cfg.model_path!r} is not a local directory: random-initialising "
                               f"the {cfg.geometry} architecture (no network / HF cache in this environment)")
                 state_dict = Weights.random_state_dict(g, dev, seed=cfg.init_seed)
-        weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora))
+        weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora) or full_ft)
         lora_state = {k: v for k, v in state_dict.items() if ".lora_" in k} or None
         if head_state is None and all(n in state_dict for n in HEAD_PARAMS):
             head_state = {n: state_dict[n] for n in HEAD_PARAMS}
@@ -174,7 +170,10 @@ class VLBLitModule(_Base):
         self.layer_norm1 = self.head
         self.layer_norm2 = self.head
         self.dropout = _Attr(p=cfg.dropout_rate)
-        self.lora = None
+        self.lora = self.full = None
+        if full_ft:
+            from .fullft import FullFineTune
+            self.full = FullFineTune(g, self.backbone, dev)
         if cfg.use_lora:
             from .lora import LoraState
             lora_sd = None if head_state is None and lora_state is None else {**(head_state or {}), **(lora_state or {})}
@@ -187,6 +186,9 @@ class VLBLitModule(_Base):
         out = [(n, self.head.master[n]) for n in HEAD_PARAMS]
         if self.lora is not None:
             out += self.lora.named_masters()
+        if self.full is not None:       # full fine-tune: every backbone tensor outside the vision tower (kernel layouts)
+            f = self.full.flat
+            out += [(f"backbone.{n}", f.view(f.master, n)) for n in f.offsets]
         return out
 
     def parameters(self):
@@ -198,6 +200,8 @@ class VLBLitModule(_Base):
         sd = {n: self.head.master[n].detach().cpu().clone() for n in HEAD_PARAMS}
         if self.lora is not None:
             sd.update({n: t.cpu() for n, t in self.lora.state_dict().items()})
+        if self.full is not None:
+            sd.update(self.full.state_dict())
         return sd
 
     def load_trainable_state_dict(self, sd: dict) -> None:
@@ -207,6 +211,7 @@ class VLBLitModule(_Base):
             self.head.compute[n].copy_(self.head.master[n])
         if self.lora is not None:
             self.lora.load_state_dict(sd)
+        # full fine-tune: the backbone masters travel as the flat store itself (trainer.trainable_state 'stores')
 
     # ------------------------------------------------------------------ dropout randomness (counter based)
     def _dropout_seed(self) -> int:
@@ -238,7 +243,7 @@ class VLBLitModule(_Base):
             x_video = torch.stack([v[0] if isinstance(v, (list, tuple)) else v for v in x_video])
         return x_video.to(self.device, torch.float32).contiguous()
 
-    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None, layout=None):
+    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None, layout=None, ids_host=None):
         """reference :229-256 -> (regression_output fp32 [B,V], l2_reg).  attention_mask is re-derived
         on the device from the ids (ids != 0), exactly what the reference passes in (:271).
         ``layout``: packed RowLayout from ``backbone.row_layout`` (rows without padded tails)."""
@@ -247,6 +252,8 @@ class VLBLitModule(_Base):
         B = ids.shape[0]
         if self.lora is not None:        # eval mode keeps the adapters (peft eval: dropout off), like the reference's validation
             hidden, key_mask = self.lora.forward(self.backbone, vis, ids, layout, train=self.training)
+        elif self.full is not None and self.training:      # full fine-tune: forward that keeps what backward needs
+            hidden, key_mask = self.full.forward(vis, ids, layout, ids_host=ids_host)
         else:
             hidden, key_mask = self.backbone.forward(vis, ids, layout=layout)
         if y is None:
@@ -267,7 +274,8 @@ class VLBLitModule(_Base):
         keep = None
         if train and cfg.dropout_rate > 0:          # nn.Dropout(p) in training mode (reference :226,251)
             keep = ops.dropout_keep_scale(x_lang.shape[0], g.dim, cfg.dropout_rate, self._dropout_seed(), dev)
-        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout)
+        ids_host = batch["language"] if batch["language"].device.type == "cpu" else None
+        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout, ids_host=ids_host)
         return pred, y, self._loss_terms
 
     def training_step(self, batch):
@@ -277,13 +285,20 @@ class VLBLitModule(_Base):
         if self.lora is not None:
             self.lora.rank = self.rank
         pred, y, terms = self._common_step(batch, train=True)
-        need_dh = self.lora is not None
+        need_dh = self.lora is not None or self.full is not None
         inv_world = 1.0 / self.world_size
         dh = self.head.backward(need_dhidden=need_dh, loss_scale=inv_world, l2_scale=inv_world)
-        if need_dh:
+        if self.lora is not None:
             self.lora.backward(self.backbone, dh)
+        elif self.full is not None:
+            self.full.backward(dh)
         for n, p in self.trainable_named_parameters():
-            p.grad = self.head.grads[n] if n in self.head.grads else self.lora.grads[n]
+            if n in self.head.grads:
+                p.grad = self.head.grads[n]
+            elif n.startswith("backbone."):
+                continue        # bf16 gradients (like the reference's bf16 parameters'): read them with self.full.flat.g_(name)
+            else:
+                p.grad = self.lora.grads[n]
         loss = terms[2]
         self.log("train/brain_loss", loss)
         return loss
@@ -306,10 +321,13 @@ class VLBLitModule(_Base):
         if getattr(self, "flat", None) is None:
             self.flat = FlatTrainables(self)          # masters / bf16 copies / grads / moments -> flat buffers
         named = self.trainable_named_parameters()
-        self.optimizer = VlbAdamW(named, self.flat, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
+        flats = [self.flat] + ([self.full.flat] if self.full is not None else [])
+        self.optimizer = VlbAdamW(named, flats, lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
                                   weight_decay=cfg.weight_decay, max_norm=cfg.gradient_clip_val)
         if self.lora is not None:
             self.optimizer.post_step.append(self.lora.refresh)
+        if self.full is not None:
+            self.optimizer.post_step.append(self.full.refresh_transposed)
         self.lr_scheduler_args = {"last_epoch": cfg.last_epoch, "T_max": cfg.t_max}
         self.scheduler = getattr(torch.optim.lr_scheduler, cfg.lr_scheduler_name)(self.optimizer, **self.lr_scheduler_args)
         return [self.optimizer], [{"scheduler": self.scheduler, "interval": "step", "frequency": 1}]

@@ -390,3 +390,96 @@ def cast_bf16(x_f32):
     out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
     check(lib.vlb_cast_f32_to_bf16(_dev(x_f32).data_ptr(), out.data_ptr(), x_f32.numel(), _stream()), "vlb_cast_f32_to_bf16")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-parameter fine-tuning pieces (csrc/train.hip)
+_ws_cache = {}
+
+
+def _ws(n_floats, device, tag="norm"):
+    """Grow-only fp32 scratch per (device, tag) for the fixed-order column reductions."""
+    key = (device.index, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = _ws_cache[key] = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+    return buf
+
+
+def transpose_pad(x, out, rows_pad):
+    """out[C, :rows_pad] = x[R, C]^T, columns R..rows_pad-1 zeroed (x may be a column slice: row stride respected)."""
+    R, C = x.shape
+    assert out.shape[0] >= C and out.stride(1) == 1 and x.stride(1) == 1 and rows_pad % 8 == 0 and out.shape[1] >= rows_pad
+    check(lib.vlb_transpose_pad(_dev(x).data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, C, rows_pad, _stream()),
+          "vlb_transpose_pad")
+    return out
+
+
+def rmsnorm_bwd_dw(x, dy, eps, out):
+    rows, dim = x.shape
+    ws = _ws(lib.vlb_norm_bwd_ws_floats(rows, dim), x.device)
+    check(lib.vlb_rmsnorm_bwd_dw(_dev(x).data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, dim, eps, _stream()),
+          "vlb_rmsnorm_bwd_dw")
+    return out
+
+
+def layernorm_bwd(x, w, b, dy, eps, dw_out, db_out, residual=None, act=ACT_NONE, want_dres=False):
+    """Backward of ``layernorm(x, w, b, eps, residual, act)``: returns (dx, d residual or None); dw / db written (bf16)."""
+    rows, dim = x.shape
+    ws = _ws(lib.vlb_norm_bwd_ws_floats(rows, dim), x.device)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    check(lib.vlb_layernorm_bwd(_dev(x).data_ptr(), w.data_ptr(), b.data_ptr(), _p(residual), dy.data_ptr(), dx.data_ptr(), _p(dres),
+                                dw_out.data_ptr(), db_out.data_ptr(), ws.data_ptr(), rows, dim, eps, act, _stream()), "vlb_layernorm_bwd")
+    return dx, dres
+
+
+def act_fwd(x, act, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(lib.vlb_act_fwd(_dev(x).data_ptr(), out.data_ptr(), x.numel(), act, _stream()), "vlb_act_fwd")
+    return out
+
+
+def act_bwd(x, dy, act, out=None):
+    out = torch.empty_like(x) if out is None else out
+    check(lib.vlb_act_bwd(_dev(x).data_ptr(), dy.data_ptr(), out.data_ptr(), x.numel(), act, _stream()), "vlb_act_bwd")
+    return out
+
+
+def colsum(x, out):
+    rows, dim = x.shape
+    ws = _ws(lib.vlb_colsum_ws_floats(rows, dim), x.device)
+    check(lib.vlb_colsum(_dev(x).data_ptr(), x.stride(0), out.data_ptr(), ws.data_ptr(), rows, dim, _stream()), "vlb_colsum")
+    return out
+
+
+def embed_grad(d_embeds, tok, beg, rows, out, D):
+    """out[tok[j]] = sum of d_embeds[rows[beg[j]:beg[j+1]]] (int32 device lists built on the host)."""
+    check(lib.vlb_embed_grad(_dev(d_embeds).data_ptr(), d_embeds.stride(0), tok.data_ptr(), beg.data_ptr(), rows.data_ptr(),
+                             tok.numel(), out.data_ptr(), D, _stream()), "vlb_embed_grad")
+    return out
+
+
+def dwconv3x3_bwd_w(x, dy, N, H, W, C, out):
+    ws = _ws(lib.vlb_dwconv3x3_bwd_w_ws_floats(N, C), x.device, "dw")
+    check(lib.vlb_dwconv3x3_bwd_w(_dev(x).data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), N, H, W, C, _stream()),
+          "vlb_dwconv3x3_bwd_w")
+    return out
+
+
+def se_bwd_gate(x, dy, s, N, HW, C):
+    ds = torch.empty(N, C, dtype=BF16, device=x.device)
+    check(lib.vlb_se_bwd_gate(_dev(x).data_ptr(), dy.data_ptr(), s.data_ptr(), ds.data_ptr(), N, HW, C, _stream()), "vlb_se_bwd_gate")
+    return ds
+
+
+def se_bwd_x(dy, s, dpool, N, HW, C):
+    dx = torch.empty_like(dy)
+    check(lib.vlb_se_bwd_x(_dev(dy).data_ptr(), s.data_ptr(), _p(dpool), dx.data_ptr(), N, HW, C, _stream()), "vlb_se_bwd_x")
+    return dx
+
+
+def col2im3d(dcols, B, T, H, W, C):
+    dx = torch.empty(B * T * H * W, C, dtype=BF16, device=dcols.device)
+    check(lib.vlb_col2im3d_k2s2p1(_dev(dcols).data_ptr(), dx.data_ptr(), B, T, H, W, C, _stream()), "vlb_col2im3d_k2s2p1")
+    return dx

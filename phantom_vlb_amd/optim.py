@@ -24,6 +24,9 @@ def _stream():
 
 
 class VlbAdamW(torch.optim.Optimizer):
+    """``flat``: one flat store or a list of them (head + LoRA: fp32 gradients; ``fullft.FlatBackbone``: bf16
+    gradients, attribute ``grad_bf16``).  One clip norm over all of them, one AdamW launch per store."""
+
     def __init__(self, named_params, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  max_norm: float = 0.0):
         named_params = list(named_params)
@@ -33,32 +36,40 @@ class VlbAdamW(torch.optim.Optimizer):
             assert p.dtype == torch.float32 and p.is_cuda and p.is_contiguous()
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_norm = float(max_norm)
-        self.flat = flat                  # FlatTrainables: masters / bf16 copies / grads / moments
-        self.sharded = None               # parallel.ShardedFlatState under data parallelism (1/world of every buffer)
+        self.flats = list(flat) if isinstance(flat, (list, tuple)) else [flat]
+        self.flat = self.flats[0]         # head (+ LoRA) store
+        self.shardeds = [None] * len(self.flats)      # parallel.ShardedFlatState per store under data parallelism
         dev = params[0].device
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.sumsq_ws = torch.zeros(lib.vlb_sumsq_ws_floats(), dtype=torch.float32, device=dev)
+        self.sumsq_ws = torch.zeros(max(lib.vlb_sumsq_ws_floats(), 1024), dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.post_step = []           # callables run after every update (e.g. LoRA derived layouts)
+        self.post_step = []           # callables run after every update (e.g. LoRA derived layouts, W^T refresh)
+
+    @property
+    def sharded(self):
+        return self.shardeds[0]
 
     def attach_sharded(self, state):
         """Data parallelism: gradients are reduce-scattered, this rank updates its 1/world slice of every segment
-        and the bf16 copies are all-gathered (parallel.ShardedFlatState)."""
-        assert state.flat is self.flat
-        self.sharded = state
+        and the bf16 copies are all-gathered (parallel.ShardedFlatState); one state per flat store."""
+        i = [k for k, f in enumerate(self.flats) if f is state.flat]
+        assert i, "attach_sharded: the state wraps a flat store this optimiser does not own"
+        self.shardeds[i[0]] = state
 
-    def full_state(self, name: str):
-        """Full-size flat fp32 buffer 'master' | 'm' | 'v' (gathered from the shards under data parallelism)."""
-        return self.sharded.gather_full(name) if self.sharded is not None else getattr(self.flat, name)
+    def full_state(self, name: str, index: int = 0):
+        """Full-size flat fp32 buffer 'master' | 'm' | 'v' of store `index` (gathered from the shards under data parallelism)."""
+        sh = self.shardeds[index]
+        return sh.gather_full(name) if sh is not None else getattr(self.flats[index], name)
 
-    def load_full_state(self, name: str, full):
-        full = full.to(self.flat.master.device)
-        if self.sharded is not None:
-            self.sharded.load_full(name, full)
+    def load_full_state(self, name: str, full, index: int = 0):
+        f, sh = self.flats[index], self.shardeds[index]
+        full = full.to(f.master.device)
+        if sh is not None:
+            sh.load_full(name, full)
             if name == "master":
-                self.flat.master.copy_(full)
+                f.master.copy_(full)
         else:
-            getattr(self.flat, name).copy_(full)
+            getattr(f, name).copy_(full)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,22 +77,27 @@ class VlbAdamW(torch.optim.Optimizer):
         group = self.param_groups[0]
         self.step_count += 1
         st = _stream()
-        sh = self.sharded
-        if sh is not None:
-            sh.finish_reduce()               # reduce-scatters started under backward + the rest (head)
-        f = sh if sh is not None else self.flat
+        for sh in self.shardeds:
+            if sh is not None:
+                sh.finish_reduce()           # reduce-scatters started under backward + the rest
+        bufs = [sh if sh is not None else f for f, sh in zip(self.flats, self.shardeds)]
         self.sumsq.zero_()
         b1, b2 = group["betas"]
         if self.max_norm > 0:
-            check(lib.vlb_grad_sumsq(f.grad.data_ptr(), f.numel, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "vlb_grad_sumsq")
+            for f, b in zip(self.flats, bufs):
+                fn = lib.vlb_grad_sumsq_bf16 if getattr(f, "grad_bf16", False) else lib.vlb_grad_sumsq
+                check(fn(b.grad.data_ptr(), b.numel, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "vlb_grad_sumsq")
+            active = [sh for sh in self.shardeds if sh is not None]
+            if active:
+                active[0].all_reduce_scalar(self.sumsq)      # the clip norm covers every rank's slices
+        for f, b in zip(self.flats, bufs):
+            fn = lib.vlb_adamw_step_g16 if getattr(f, "grad_bf16", False) else lib.vlb_adamw_step
+            check(fn(b.master.data_ptr(), b.compute.data_ptr(), b.grad.data_ptr(), b.m.data_ptr(), b.v.data_ptr(), b.numel,
+                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), self.step_count,
+                     self.sumsq.data_ptr(), self.max_norm, st), "vlb_adamw_step")
+        for sh in self.shardeds:
             if sh is not None:
-                sh.all_reduce_scalar(self.sumsq)      # the clip norm covers every rank's slices
-        check(lib.vlb_adamw_step(f.master.data_ptr(), f.compute.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(),
-                                 f.v.data_ptr(), f.numel, float(group["lr"]), float(b1), float(b2),
-                                 float(group["eps"]), float(group["weight_decay"]), self.step_count,
-                                 self.sumsq.data_ptr(), self.max_norm, st), "vlb_adamw_step")
-        if sh is not None:
-            sh.gather_compute()
+                sh.gather_compute()
         for fn in self.post_step:
             fn()
         return loss

@@ -128,7 +128,7 @@ class ShardedFlatState:
             dev = flat.master.device
             self.master = torch.empty(off, dtype=torch.float32, device=dev)
             self.compute = torch.empty(off, dtype=flat.compute.dtype, device=dev)
-            self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.grad = torch.zeros(off, dtype=flat.grad.dtype, device=dev)      # fp32, or bf16 for the backbone store
             self.m = torch.zeros(off, dtype=torch.float32, device=dev)
             self.v = torch.zeros(off, dtype=torch.float32, device=dev)
             self.load_masters()
@@ -210,14 +210,18 @@ class ShardedFlatState:
 
 def attach_data_parallel(module, optimizer, group=None, comm=None, force_collectives: bool = False):
     """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism with sharded optimiser state."""
-    flat = module.flat
     if comm is None:
         comm = make_comm(group)
-    state = ShardedFlatState(flat, comm, force_collectives=force_collectives)
+    state = ShardedFlatState(module.flat, comm, force_collectives=force_collectives)
     optimizer.attach_sharded(state)
-    for owner in (getattr(module, "lora", None), getattr(module, "full", None)):
-        if owner is not None:
-            owner.grad_hook = state.on_layer_done
+    lora, full = getattr(module, "lora", None), getattr(module, "full", None)
+    if lora is not None:
+        lora.grad_hook = state.on_layer_done
+    module.sharded_backbone = None
+    if full is not None:            # full fine-tune: the backbone store is sharded the same way (bf16 gradients)
+        sb = module.sharded_backbone = ShardedFlatState(full.flat, comm, force_collectives=force_collectives)
+        optimizer.attach_sharded(sb)
+        full.grad_hook = sb.on_layer_done
     module.world_size, module.rank = state.world, state.rank
     module.sharded = state
     return state
@@ -248,6 +252,15 @@ def sync_module_states(module, src: int = 0, group=None):
         sharded = getattr(module, "sharded", None)
         if sharded is not None:
             sharded.load_masters()
+        full = getattr(module, "full", None)
+        if full is not None:
+            broadcast_parameters([full.flat.compute], src, group)      # bf16 weights; masters are their exact widening
+            step = 1 << 28
+            for a in range(0, full.flat.numel, step):
+                full.flat.master[a:a + step].copy_(full.flat.compute[a:a + step])
+            if getattr(module, "sharded_backbone", None) is not None:
+                module.sharded_backbone.load_masters()
+            full.refresh_transposed()
     else:
         broadcast_parameters(module.parameters(), src, group)
         for n, t in module.head.master.items():

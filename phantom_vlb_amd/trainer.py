@@ -64,6 +64,8 @@ def trainable_state(module, step: int) -> dict:
         state.update(exp_avg=opt.full_state("m").cpu(), exp_avg_sq=opt.full_state("v").cpu(), opt_step=opt.step_count,
                      flat_offsets={n: (o, k) for n, (o, k, _) in module.flat.offsets.items()},
                      lr=opt.param_groups[0]["lr"])
+        # further flat stores (full fine-tune: the backbone in kernel layouts) travel whole: master + both moments
+        state["stores"] = [{k: opt.full_state(k, i).cpu() for k in ("master", "m", "v")} for i in range(1, len(opt.flats))]
     sch = getattr(module, "scheduler", None)
     if sch is not None:
         state["lr_scheduler"] = sch.state_dict()
@@ -110,6 +112,15 @@ def load_trainable_checkpoint(module, path):
         opt.load_full_state("m", st["exp_avg"])
         opt.load_full_state("v", st["exp_avg_sq"])
         opt.step_count = st["opt_step"]
+        for i, store in enumerate(st.get("stores", []), start=1):
+            for k in ("master", "m", "v"):
+                opt.load_full_state(k, store[k], i)
+            f = opt.flats[i]
+            step = 1 << 28
+            for a in range(0, f.numel, step):
+                f.compute[a:a + step].copy_(f.master[a:a + step])
+        for fn in opt.post_step:
+            fn()                          # derived layouts (LoRA A^T / B pads, W^T copies) from the restored weights
     sch = getattr(module, "scheduler", None)
     if sch is not None and "lr_scheduler" in st:
         sch.load_state_dict(st["lr_scheduler"])
