@@ -32,7 +32,7 @@ GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 2.495e9,     # default (LoRA, packe
                         (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows: ..._frozen_w4.csv
                         (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: ..._traffic.csv
 # algorithmic TFLOP per clip
-TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8}
+TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8, "full": 100.8}
 
 
 def parse():
@@ -40,8 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="lora", choices=["frozen", "lora"],
-                    help="lora = BASELINE configs[2], the configuration the metric names (default); frozen = configs[1]")
+    ap.add_argument("--workload", default="lora", choices=["frozen", "lora", "full"],
+                    help="lora = BASELINE configs[2], the configuration the metric names (default); frozen = configs[1]; "
+                         "full = configs[4]'s model side on the GPUs given: full-parameter fine-tune, 65k-voxel head")
+    ap.add_argument("--num-target", type=int, default=0, help="head width (default 2048; 65536 for --workload full)")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
     ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -176,12 +178,13 @@ def main():
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
 
-    lora = a.workload == "lora"
-    B = a.batch or (3 if lora else 5)
+    lora, full = a.workload == "lora", a.workload == "full"
+    B = a.batch or (5 if a.workload == "frozen" else 3)
+    num_target = a.num_target or (65536 if full else 2048)
     cfg = VLBLitModuleConfig(
-        model_path="DAMO-NLP-SG/VideoLLaMA2-7B", freeze_backbone=not lora, use_lora=lora,
+        model_path="DAMO-NLP-SG/VideoLLaMA2-7B", freeze_backbone=a.workload == "frozen", use_lora=lora,
         lora_r=16 if lora else None, lora_alpha=32 if lora else None, lora_dropout=0.1 if lora else None,
-        dropout_rate=0.1, num_target=2048 if a.geometry == "7b" else 128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999],
+        dropout_rate=0.1, num_target=num_target if a.geometry == "7b" else 128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999],
         eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000,
         geometry=a.geometry, pack_tokens=not a.no_pack)
     import warnings
@@ -244,8 +247,10 @@ def main():
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16"
-                                    if not lora else "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16")
+            "config": {"workload": {"frozen": "configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16",
+                                    "lora": "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16",
+                                    "full": f"configs[4] model side: VideoLLaMA2-7B full-parameter fine-tune (all but the vision tower), "
+                                            f"{num_target}-voxel head, bf16 GEMMs"}[a.workload]
                        if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
                        "num_target": cfg.num_target, "weights": "random-init",
@@ -267,10 +272,11 @@ def main():
                          "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
                          "traffic_note": "L2->fabric bytes of the main launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic*.csv); "
                          + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN:.3e} (A | t, W | B, C [M,N] bf16)" if lora else
+                            f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
         }
-        if world == 1 and not a.no_cpu_baseline and a.geometry == "7b":
+        if world == 1 and not a.no_cpu_baseline and a.geometry == "7b" and not full:
             out["cpu_baseline"] = cpu_baseline(cfg.num_target, lora)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -339,6 +339,18 @@ int vlb_se_bwd_x(const void* dy, const void* s, const void* dpool, void* dx, int
 int vlb_col2im3d_k2s2p1(const void* dcols, void* dx, int B, int T, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * fp8 MFMA GEMMs (BASELINE configs[4]): OCP e4m3 elements with one E8M0 scale (2^(s-127)) per 32 consecutive K
+ * elements - the MX block format v_mfma_scale_f32_16x16x128_f8f6f4 consumes at twice the bf16 MFMA rate.
+ */
+/* x bf16 [rows, K] -> q uint8 [rows, K] (e4m3, round-to-nearest-even, saturating) + scales uint8 [rows, K/32];
+ * the shared exponent of a block is ceil(log2(amax / 448)).  K % 32 == 0; ld* in elements of the respective array. */
+int vlb_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int rows, int K, void* stream);
+/* C[M,N] bf16 = dequant(Aq,sA)[M,K] . dequant(Wq,sW)[N,K]^T + residual (optional); fp32 accumulate.
+ * N % 256 == 0, K % 128 == 0, any M. */
+int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa, const void* Wq, int ldw, const void* sW, int ldsw, void* C,
+                   int ldc, int M, int N, int K, const void* residual, int ldr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Exchange steps of the sharded training step over RCCL / xGMI - what an fsdp.yaml-driven run of the reference
  * (fsdp.yaml:5-14 FULL_SHARD; never loaded by its mainline) would issue through torch FSDP's NCCL calls:
  * parameter all-gather, gradient reduce-scatter, the clip norm's scalar all-reduce.  "direct" = all-pairs

@@ -1,0 +1,273 @@
+// Block-scaled fp8 (MX: OCP e4m3 elements, one E8M0 scale per 32 consecutive K elements) MFMA GEMM for gfx950:
+//   C[M,N] (bf16) = dequant(Aq, sA)[M,K] . dequant(Wq, sW)[N,K]^T (+ residual)
+// on v_mfma_scale_f32_16x16x128_f8f6f4 - the instruction that reaches the fp8 rate (2x the bf16 MFMA rate per clock;
+// the unscaled fp8 MFMAs run at the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  BASELINE configs[4] asks for
+// fp8 MFMA GEMMs on the full fine-tune's linears; vlb_quantize_mxfp8 produces the operands from bf16.
+//
+// Kernel: 256x256 output tile, K step 128 (= one MFMA K), 512 threads = 2(M) x 4(N) waves of 128x64; operands go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double-buffered image of 128-byte rows whose 16-byte
+// chunks are XOR-swizzled on the SOURCE address (chunk c of row r at slot c ^ ((r>>1)&7)).  Operand layout of the
+// instruction, measured with exact data (tools/probe_mfma_scale.py): lane l = (row l&15, group g = l>>4) holds
+// k = 16g..16g+15 in its first 16 bytes and k = 64+16g..64+16g+15 in its second 16 bytes (two ds_read_b128: chunks g
+// and 4+g of the row), while the E8M0 scale it supplies is the one of 32-element block g (k = 32g..32g+31) of its
+// row; both operands' scales are bytes of ONE register (see the K loop).  MFMA roles are swapped like in the
+// bf16 kernel (MFMA rows = output columns) so a lane owns 4 consecutive n of one output row: 8-byte stores.
+// Scales: one byte per (row, 32-element K block), read straight from global (L2-resident) one K-tile ahead.
+#include "common.hpp"
+
+namespace {
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct Fp8Args {
+  const uint8_t* A; const uint8_t* sA; const uint8_t* W; const uint8_t* sW;
+  bf16* C; const bf16* residual;
+  int M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, tiles_m, tiles_n;
+};
+
+constexpr int FBK = 128;            // K bytes per tile row
+constexpr int FROW = 128;           // LDS row bytes
+__device__ __forceinline__ int f_off(int r, int c) { return r * FROW + ((c ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ void glds16f(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(Fp8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = 256 * FROW, STAGE = 2 * A_BYTES;       // 64 KB per stage, 2 stages
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  // ---- tile order: XCD-contiguous runs (blocks b and b+8 share an XCD), bands of 4 row tiles
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int t;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int band = t / (4 * p.tiles_n), within = t - band * 4 * p.tiles_n;
+  const int band_rows = min(4, p.tiles_m - band * 4);
+  const int tm = band * 4 + within % band_rows, tn = within / band_rows;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = p.K / FBK;
+
+  // ---- LDS-DMA: a wave instruction writes 1 KiB = 8 rows x 128 B; thread -> (row, slot); source chunk = slot ^ swz(row)
+  // per K-tile and operand: 256 rows = 32 pieces; 8 waves x 4 pieces
+  const char* srcA[4]; const char* srcW[4];
+  int dstoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = wave * 4 + j;
+    const int r = piece * 8 + (lane >> 3), s = lane & 7;
+    const int c = s ^ ((r >> 1) & 7);
+    srcA[j] = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * p.lda + c * 16;
+    srcW[j] = reinterpret_cast<const char*>(p.W) + (int64_t)(n0 + r) * p.ldw + c * 16;
+    dstoff[j] = piece * 1024;                       // + lane*16 is added by the hardware
+  }
+  auto stage = [&](int st, int kt) {
+    char* base = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16f(srcA[j] + (int64_t)kt * FBK, base + dstoff[j]);
+      glds16f(srcW[j] + (int64_t)kt * FBK, base + A_BYTES + dstoff[j]);
+    }
+  };
+  // ---- fragments and scales
+  const int fr = lane & 15, g = lane >> 4;
+  const uint8_t* sa_ptr[8]; const uint8_t* sw_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sa_ptr[i] = p.sA + (int64_t)min(m0 + wm * 128 + i * 16 + fr, p.M - 1) * p.ldsa + g;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sw_ptr[j] = p.sW + (int64_t)(n0 + wn * 64 + j * 16 + fr) * p.ldsw + g;
+  int sa_cur[8], sw_cur[4], sa_nxt[8], sw_nxt[4];
+  auto load_scales = [&](int kt, int (&sa)[8], int (&sw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa[i] = sa_ptr[i][kt * 4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[j] = sw_ptr[j][kt * 4];
+  };
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  load_scales(0, sa_cur, sw_cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) { stage((kt + 1) & 1, kt + 1); load_scales(kt + 1, sa_nxt, sw_nxt); }
+    const char* sb = smem + (kt & 1) * STAGE;
+    i32x8 wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wn * 64 + j * 16 + fr;
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, g));
+      const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, 4 + g));
+      wf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      i32x8 af[4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int r = wm * 128 + (half * 4 + ii) * 16 + fr;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + f_off(r, g));
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + f_off(r, 4 + g));
+        af[ii] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // Both E8M0 scales travel in ONE register: byte 0 = the MFMA-A operand's (the W rows), byte 1 = the MFMA-B
+          // operand's (the activation rows), selected by op_sel 0 / 1.  Measured on gfx950 with ROCm 7.2
+          // (tools/probe_mfma_scale.py): the instruction takes both scale bytes from the register in the scale_b
+          // position and ignores the scale_a register; passing the same packed register in both positions is right
+          // under either reading.
+          const int sc = sw_cur[j] | (sa_cur[half * 4 + ii] << 8);
+          acc[j][half * 4 + ii] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[ii], acc[j][half * 4 + ii], 0, 0, 0, sc, 1, sc);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt+1 (and its scales) landed
+    __syncthreads();                                        // everyone is done reading stage kt&1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa_cur[i] = sa_nxt[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw_cur[j] = sw_nxt[j];
+  }
+  // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      f32x4 v = acc[j][i];
+      if (p.residual) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- bf16 -> MX fp8 (e4m3 + E8M0 block scales)
+// One thread per 32-element block: amax -> shared exponent E = ceil(log2(amax / 448)) clamped to [-127, 127];
+// scale byte = E + 127; elements = RNE(x * 2^-E) saturated to +-448 (OCP e4m3fn: no infinities).
+__device__ __forceinline__ uint8_t f32_to_e4m3(float x) {
+  // round-to-nearest-even into e4m3fn (bias 7, 3 mantissa bits, max 448, subnormal step 2^-9)
+  const uint32_t sign = (__float_as_uint(x) >> 24) & 0x80u;
+  float a = fabsf(x);
+  if (!(a == a)) return (uint8_t)(sign | 0x7f);             // NaN
+  if (a >= 448.f) return (uint8_t)(sign | 0x7e);            // saturate to the largest finite value
+  if (a < 0.0009765625f) return (uint8_t)sign;              // below half the smallest subnormal (2^-10): zero
+  int e; (void)frexpf(a, &e);                               // a = f * 2^e, f in [0.5, 1)
+  int exp_unb = e - 1;                                      // a = 1.m * 2^exp_unb
+  if (exp_unb < -6) exp_unb = -6;                           // subnormal range shares the exponent of the smallest normal
+  const float q = rintf(a * exp2f((float)(3 - exp_unb)));   // mantissa steps of 2^(exp_unb-3), RNE (rintf)
+  float r = q * exp2f((float)(exp_unb - 3));
+  if (r >= 448.f) return (uint8_t)(sign | 0x7e);
+  if (r == 0.f) return (uint8_t)sign;
+  (void)frexpf(r, &e);
+  int eu = e - 1;
+  uint32_t bits;
+  if (eu < -6) bits = (uint32_t)rintf(r * 512.f);           // subnormal: value = m * 2^-9
+  else bits = ((uint32_t)(eu + 7) << 3) | ((uint32_t)rintf(r * exp2f((float)(3 - eu))) & 7u);
+  return (uint8_t)(sign | bits);
+}
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+                                                            uint8_t* __restrict__ s, int lds_, int rows, int kblocks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * kblocks) return;
+  const int r = (int)(i / kblocks), kb = (int)(i % kblocks);
+  const bf16* xp = x + (int64_t)r * ldx + kb * 32;
+  float v[32];
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(xp + c * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[c * 8 + k] = (float)t[k]; amax = fmaxf(amax, fabsf(v[c * 8 + k])); }
+  }
+  int E = -127;
+  if (amax > 0.f) {
+    int e; const float f = frexpf(amax / 448.f, &e);        // amax/448 = f * 2^e, f in [0.5,1)
+    E = (f == 0.5f) ? e - 1 : e;                            // ceil(log2(amax/448))
+    E = max(-127, min(127, E));
+  }
+  s[(int64_t)r * lds_ + kb] = (uint8_t)(E + 127);
+  const float inv = exp2f((float)-E);
+  uint32_t w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t pk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk |= (uint32_t)f32_to_e4m3(v[c * 4 + k] * inv) << (8 * k);
+    w[c] = pk;
+  }
+  u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)r * ldq + kb * 32);
+  qp[0] = u32x4{w[0], w[1], w[2], w[3]};
+  qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+}
+}  // namespace
+
+#ifdef VLB_TOOLS
+// tools build only: ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-given per-lane registers (layout experiments)
+namespace {
+template <int OA, int OB>
+__global__ void mfma_scale_probe_kernel(const int* a, const int* b, const int* sa, const int* sb, float* d) {
+  const int l = threadIdx.x;
+  i32x8 av, bv;
+  for (int i = 0; i < 8; ++i) { av[i] = a[l * 8 + i]; bv[i] = b[l * 8 + i]; }
+  f32x4 c = {d[l * 4], d[l * 4 + 1], d[l * 4 + 2], d[l * 4 + 3]};
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, OA, sa[l], OB, sb[l]);
+  for (int i = 0; i < 4; ++i) d[l * 4 + i] = c[i];
+}
+}  // namespace
+extern "C" int vlb_mfma_scale_probe(const int* a, const int* b, const int* sa, const int* sb, float* d, int mode, void* stream) {
+  hipStream_t st = as_stream(stream);
+  if (mode == 0) hipLaunchKernelGGL((mfma_scale_probe_kernel<0, 0>), dim3(1), dim3(64), 0, st, a, b, sa, sb, d);
+  if (mode == 1) hipLaunchKernelGGL((mfma_scale_probe_kernel<0, 1>), dim3(1), dim3(64), 0, st, a, b, sa, sb, d);
+  if (mode == 2) hipLaunchKernelGGL((mfma_scale_probe_kernel<1, 0>), dim3(1), dim3(64), 0, st, a, b, sa, sb, d);
+  if (mode == 3) hipLaunchKernelGGL((mfma_scale_probe_kernel<2, 3>), dim3(1), dim3(64), 0, st, a, b, sa, sb, d);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+#endif
+
+extern "C" int vlb_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int rows, int K, void* stream) {
+  VLB_REQUIRE(x_bf16 && q && scales && rows > 0 && K > 0 && K % 32 == 0 && ldx % 8 == 0 && ldq % 16 == 0 && ldx >= K && ldq >= K && lds >= K / 32,
+              "quantize_mxfp8: K must be a multiple of 32, ldx of 8, ldq of 16");
+  VLB_REQUIRE((((uintptr_t)x_bf16 | (uintptr_t)q) % 16) == 0, "quantize_mxfp8: 16-byte alignment required");
+  const int kb = K / 32;
+  const int64_t total = (int64_t)rows * kb;
+  hipLaunchKernelGGL(quantize_mxfp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx,
+                     (uint8_t*)q, ldq, (uint8_t*)scales, lds, rows, kb);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa, const void* Wq, int ldw, const void* sW, int ldsw, void* C,
+                              int ldc, int M, int N, int K, const void* residual, int ldr, void* stream) {
+  VLB_REQUIRE(Aq && sA && Wq && sW && C, "gemm_mxfp8: null operand");
+  VLB_REQUIRE(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 128 == 0, "gemm_mxfp8: needs N %% 256 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
+  VLB_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldsa >= K / 32 && ldsw >= K / 32 && ldc % 4 == 0 && ldc >= N,
+              "gemm_mxfp8: bad leading dimensions");
+  VLB_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq) % 16) == 0 && ((uintptr_t)C % 8) == 0, "gemm_mxfp8: misaligned operand");
+  if (residual) VLB_REQUIRE(ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0, "gemm_mxfp8: bad residual");
+  Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
+            M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + 255) / 256, N / 256};
+  constexpr int LDS = 2 * 2 * 256 * 128;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
+  hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, as_stream(stream), a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}

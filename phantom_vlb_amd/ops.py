@@ -483,3 +483,29 @@ def col2im3d(dcols, B, T, H, W, C):
     dx = torch.empty(B * T * H * W, C, dtype=BF16, device=dcols.device)
     check(lib.vlb_col2im3d_k2s2p1(_dev(dcols).data_ptr(), dx.data_ptr(), B, T, H, W, C, _stream()), "vlb_col2im3d_k2s2p1")
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# block-scaled fp8 (MX e4m3) GEMM path (csrc/gemm_fp8.hip)
+def quantize_mxfp8(x, q=None, s=None):
+    """bf16 [rows, K] -> (uint8 e4m3 [rows, K], uint8 E8M0 scales [rows, K/32]); x may be a column slice."""
+    rows, K = x.shape
+    assert K % 32 == 0 and x.stride(1) == 1
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device) if q is None else q
+    s = torch.empty(rows, K // 32, dtype=torch.uint8, device=x.device) if s is None else s
+    check(lib.vlb_quantize_mxfp8(_dev(x).data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), rows, K, _stream()),
+          "vlb_quantize_mxfp8")
+    return q, s
+
+
+def gemm_mxfp8(aq, sa, wq, sw, residual=None, out=None):
+    """out[M,N] bf16 = dequant(aq, sa) @ dequant(wq, sw)^T + residual."""
+    M, K = aq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and sa.shape == (M, K // 32) and sw.shape == (N, K // 32)
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=aq.device)
+    check(lib.vlb_gemm_mxfp8(_dev(aq).data_ptr(), aq.stride(0), sa.data_ptr(), sa.stride(0), wq.data_ptr(), wq.stride(0), sw.data_ptr(),
+                             sw.stride(0), out.data_ptr(), out.stride(0), M, N, K, _p(residual),
+                             residual.stride(0) if residual is not None else 0, _stream()), "vlb_gemm_mxfp8")
+    return out

@@ -1,0 +1,75 @@
+"""Block-scaled fp8 (MX: e4m3 + E8M0 per 32 K elements) MFMA GEMM, BASELINE configs[4]: the quantiser bit-for-bit
+against a torch restatement of the OCP MX rule, the GEMM against an fp32 matmul of the dequantised operands, and the
+parity ladder fp32 -> bf16 MFMA -> fp8 MFMA on decoder-sized operands."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _quant_ref(x):
+    """x fp32 [R, K] (bf16-valued) -> (uint8 e4m3 bytes, uint8 scales, dequantised fp32)."""
+    R, K = x.shape
+    xb = x.view(R, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    E = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).clamp(-127, 127), torch.full_like(amax, -127).double()).float()
+    scaled = xb * torch.exp2(-E)[..., None]
+    q = scaled.to(torch.float8_e4m3fn)
+    deq = (q.float() * torch.exp2(E)[..., None]).view(R, K)
+    return q.view(torch.uint8).view(R, K), (E + 127).to(torch.uint8), deq
+
+
+def test_quantize_mxfp8_bit_exact(dev):
+    from phantom_vlb_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(300, 256) * torch.logspace(-6, 3, 300)[:, None]).to(BF)
+    x[5] = 0                                     # an all-zero row: scale byte 0, zero elements
+    x[6, :32] = 448.0                            # exactly representable extremes
+    x[7, 3] = 2.0 ** -20                         # far below the block's resolution: flushes to zero
+    qr, sr, _ = _quant_ref(x.float())
+    q, s = ops.quantize_mxfp8(x.to(dev))
+    assert torch.equal(s.cpu(), sr)
+    qc = q.cpu()
+    same = (qc == qr) | ((qc & 0x7f) == 0) & ((qr & 0x7f) == 0)       # +0 / -0 are the same value
+    assert bool(same.all()), int((~same).sum())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (5861, 1024, 4096), (77, 256, 256)])
+def test_gemm_mxfp8_equals_fp32_matmul_of_the_dequantised_operands(dev, M, N, K):
+    from phantom_vlb_amd import ops
+    torch.manual_seed(1)
+    a = (torch.randn(M, K) * torch.rand(M, 1).mul(4).exp()).to(BF)          # rows with very different magnitudes
+    w = (torch.randn(N, K) * 0.05).to(BF)
+    r = torch.randn(M, N).to(BF)
+    aq, sa = ops.quantize_mxfp8(a.to(dev))
+    wq, sw = ops.quantize_mxfp8(w.to(dev))
+    _, _, ad = _quant_ref(a.float())
+    _, _, wd = _quant_ref(w.float())
+    ref = ad.double() @ wd.double().t()
+    out = ops.gemm_mxfp8(aq, sa, wq, sw)
+    assert rel_err(out, ref.float()) < 6e-3                                   # bf16 output rounding only
+    out_r = ops.gemm_mxfp8(aq, sa, wq, sw, residual=r.to(dev))
+    assert rel_err(out_r, (ref + r.double()).float()) < 6e-3
+
+
+def test_parity_ladder_fp32_bf16_fp8(dev):
+    """Same operands through fp32 matmul, the bf16 MFMA GEMM and the MX-fp8 MFMA GEMM: relative error (vs max |ref|)
+    of the bf16 path ~1e-3 (output rounding), of the fp8 path a few 1e-2 of the output RMS - the ladder DESIGN.md quotes."""
+    from phantom_vlb_amd import ops
+    torch.manual_seed(2)
+    M, N, K = 2048, 4096, 4096
+    a = torch.randn(M, K).to(BF).to(dev)
+    w = (torch.randn(N, K) * 0.02).to(BF).to(dev)
+    ref = a.float() @ w.float().t()
+    y16 = ops.gemm(a, w).float()
+    aq, sa = ops.quantize_mxfp8(a)
+    wq, sw = ops.quantize_mxfp8(w)
+    y8 = ops.gemm_mxfp8(aq, sa, wq, sw).float()
+    rms = float(ref.pow(2).mean().sqrt())
+    e16 = float((y16 - ref).pow(2).mean().sqrt()) / rms
+    e8 = float((y8 - ref).pow(2).mean().sqrt()) / rms
+    print(f"ladder: bf16 rms err {e16:.2e}, mxfp8 rms err {e8:.2e}")
+    assert e16 < 5e-3 and e16 < e8 < 6e-2
