@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--workload", default="lora", choices=["frozen", "lora", "full"],
                     help="lora = BASELINE configs[2], the configuration the metric names (default); frozen = configs[1]; "
                          "full = configs[4]'s model side on the GPUs given: full-parameter fine-tune, 65k-voxel head")
+    ap.add_argument("--fp8", action="store_true", help="--workload full: decoder forward / dgrad GEMMs on the MX-fp8 MFMA path")
     ap.add_argument("--num-target", type=int, default=0, help="head width (default 2048; 65536 for --workload full)")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default 5 frozen / 3 lora, the reference's)")
     ap.add_argument("--geometry", default="7b", choices=["7b", "mini"])
@@ -186,7 +187,7 @@ def main():
         lora_r=16 if lora else None, lora_alpha=32 if lora else None, lora_dropout=0.1 if lora else None,
         dropout_rate=0.1, num_target=num_target if a.geometry == "7b" else 128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999],
         eps=1e-8, weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000,
-        geometry=a.geometry, pack_tokens=not a.no_pack)
+        geometry=a.geometry, pack_tokens=not a.no_pack, fp8_gemm=bool(a.fp8 and full))
     import warnings
     warnings.simplefilter("ignore")
     m = VLBLitModule(cfg)
@@ -250,7 +251,7 @@ def main():
             "config": {"workload": {"frozen": "configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16",
                                     "lora": "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16",
                                     "full": f"configs[4] model side: VideoLLaMA2-7B full-parameter fine-tune (all but the vision tower), "
-                                            f"{num_target}-voxel head, bf16 GEMMs"}[a.workload]
+                                            f"{num_target}-voxel head, " + ("MX-fp8 decoder forward/dgrad GEMMs, bf16 wgrad" if a.fp8 else "bf16 GEMMs")}[a.workload]
                        if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
                        "num_target": cfg.num_target, "weights": "random-init",

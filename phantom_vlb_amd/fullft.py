@@ -117,14 +117,19 @@ class FlatBackbone:
 class FullFineTune:
     """Forward-with-save and explicit backward of connector + decoder for the full-parameter configuration."""
 
-    def __init__(self, g: Geometry, backbone, device):
+    def __init__(self, g: Geometry, backbone, device, fp8_gemm: bool = False):
+        """``fp8_gemm``: run the decoder's forward and dgrad GEMMs on the block-scaled fp8 MFMA path (MX e4m3 with
+        E8M0 scales per 32 K elements, ``vlb_gemm_mxfp8``): activations are quantised per use, the weights (and their
+        transposes) once per optimiser step; weight gradients, attention, norms and the optimiser stay as they are."""
         self.g, self.bb, self.w, self.dev = g, backbone, backbone.w, device
+        self.fp8 = bool(fp8_gemm)
+        self.wq = {}                          # (layer, key) -> (uint8 e4m3 weights, uint8 scales)
         self.flat = FlatBackbone(g, self.w)
         self.grad_hook = None                 # callable(layer index): that layer's gradients are final (data parallel)
         self._tb = {}
         # transposed copies for dgrad: the decoder's come from Weights(keep_transposed=True); the connector's are made here
         self.conn_t = {}
-        self.refresh_transposed(decoder=False)
+        self.refresh_transposed(decoder=self.fp8)
 
     # ------------------------------------------------------------------ derived layouts
     def _conn_linears(self):
@@ -149,6 +154,11 @@ class FullFineTune:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     R, C = lw[k].shape
                     check(lib.vlb_transpose_bf16(lw[k].data_ptr(), lw[k + "_t"].data_ptr(), R, C, _stream()), "vlb_transpose_bf16")
+        if self.fp8:
+            for li, lw in enumerate(self.w.layers):
+                for k in ("wqkv", "wo", "wgu", "wdown", "wqkv_t", "wo_t", "wgu_t", "wdown_t"):
+                    old = self.wq.get((li, k), (None, None))
+                    self.wq[(li, k)] = ops.quantize_mxfp8(lw[k], *old)
         dw_f = getattr(self, "dw_flipped", None)
         if dw_f is None:
             dw_f = self.dw_flipped = {}
@@ -179,6 +189,14 @@ class FullFineTune:
         dyT = self._transposed(dy, "dyT") if dyT is None else dyT
         xT = self._transposed(x, "xT") if xT is None else xT
         ops.gemm(dyT, xT, out=out)
+
+    def _lin(self, x, li, key, residual=None):
+        """x @ W^T (+ residual) for decoder weight `key` of layer li: bf16 MFMA GEMM, or the MX-fp8 one."""
+        if self.fp8:
+            xq, xs = ops.quantize_mxfp8(x)
+            wq, ws = self.wq[(li, key)]
+            return ops.gemm_mxfp8(xq, xs, wq, ws, residual=residual)
+        return ops.gemm(x, self.w.layers[li][key], residual=residual)
 
     # ------------------------------------------------------------------ connector (training forward + backward)
     def _block_fwd(self, x, blk, N, H, save):
@@ -288,15 +306,15 @@ class FullFineTune:
         self.saved = []
         for li, lw in enumerate(w.layers):
             h1 = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
-            qkv = ops.gemm(h1, lw["wqkv"])
+            qkv = self._lin(h1, li, "wqkv")
             ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
             a, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads, g.head_dim,
                                        True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True, layout=layout)
-            x2 = ops.gemm(a, lw["wo"], residual=x)
+            x2 = self._lin(a, li, "wo", residual=x)
             h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
-            gu = ops.gemm(h2, lw["wgu"])
+            gu = self._lin(h2, li, "wgu")
             hh = ops.swiglu(gu)
-            x3 = ops.gemm(hh, lw["wdown"], residual=x2)
+            x3 = self._lin(hh, li, "wdown", residual=x2)
             self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh))
             x = x3
         self.x_last, self.key_mask, self.B, self.layout = x, key_mask, B, layout
@@ -318,20 +336,20 @@ class FullFineTune:
             pre = f"layers.{li}"
             # MLP: x3 = x2 + down(silu(gate) * up)
             self.wgrad(dx, sv["hh"], G(f"{pre}.wdown"))
-            d_hh = ops.gemm(dx, lw["wdown_t"])
+            d_hh = self._lin(dx, li, "wdown_t")
             d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
             self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"))
-            d_h2 = ops.gemm(d_gu, lw["wgu_t"])
+            d_h2 = self._lin(d_gu, li, "wgu_t")
             ops.rmsnorm_bwd_dw(sv["x2"], d_h2, g.rms_eps, G(f"{pre}.post_norm"))
             dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
             # attention: x2 = x + o(attn(rope(qkv(norm(x)))))
             self.wgrad(dx2, sv["a"], G(f"{pre}.wo"))
-            d_a = ops.gemm(dx2, lw["wo_t"])
+            d_a = self._lin(dx2, li, "wo_t")
             dqkv = ops.attention_bwd(sv["qkv"], qd, kd, sv["a"], d_a, sv["lse"], self.key_mask, B, S, g.heads, g.kv_heads,
                                      g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta)
             ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
             self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"))
-            d_h1 = ops.gemm(dqkv, lw["wqkv_t"])
+            d_h1 = self._lin(dqkv, li, "wqkv_t")
             ops.rmsnorm_bwd_dw(sv["x"], d_h1, g.rms_eps, G(f"{pre}.in_norm"))
             dx = ops.rmsnorm_bwd(sv["x"], lw["in_norm"], d_h1, g.rms_eps, dx_in=dx2)
             self.saved[li] = None

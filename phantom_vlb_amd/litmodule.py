@@ -99,6 +99,7 @@ class VLBLitModuleConfig:
     init_seed: int = 1234
     gradient_clip_val: float = 1.0  # the Trainer's gradient_clip_val, applied inside the fused AdamW
     pack_tokens: bool = True        # drop each clip's padded tail rows (flash-attn varlen equivalent)
+    fp8_gemm: bool = False          # full fine-tune only: decoder forward / dgrad GEMMs on the MX-fp8 MFMA path (configs[4])
 
     def __post_init__(self):
         self.dtype = torch.bfloat16      # reference :155
@@ -173,7 +174,7 @@ class VLBLitModule(_Base):
         self.lora = self.full = None
         if full_ft:
             from .fullft import FullFineTune
-            self.full = FullFineTune(g, self.backbone, dev)
+            self.full = FullFineTune(g, self.backbone, dev, fp8_gemm=bool(getattr(cfg, "fp8_gemm", False)))
         if cfg.use_lora:
             from .lora import LoraState
             lora_sd = None if head_state is None and lora_state is None else {**(head_state or {}), **(lora_state or {})}

@@ -73,3 +73,38 @@ def test_parity_ladder_fp32_bf16_fp8(dev):
     e8 = float((y8 - ref).pow(2).mean().sqrt()) / rms
     print(f"ladder: bf16 rms err {e16:.2e}, mxfp8 rms err {e8:.2e}")
     assert e16 < 5e-3 and e16 < e8 < 6e-2
+
+
+def test_full_finetune_step_on_the_fp8_path_tracks_the_bf16_path(dev):
+    """Model-level rung of the ladder (configs[4] in miniature): the same full fine-tuning step with the decoder's
+    forward / dgrad GEMMs on MX-fp8 - loss within 2 % of the bf16 path's and of the fp32 oracle's, gradients
+    correlated > 0.97 with the bf16 path's, training still reduces the loss."""
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=11))
+    batch = O.synthetic_batch(g, 4, seed=12)
+    with torch.no_grad():
+        loss_ref, _ = O.training_loss(p, batch, g)
+    res = {}
+    for fp8 in (False, True):
+        cfg = VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=False, lora_r=None, lora_alpha=None, lora_dropout=None,
+                                 dropout_rate=0.0, num_target=128, l2_lambda=1e-3, lr=1e-3, betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2,
+                                 lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini", fp8_gemm=fp8)
+        m = VLBLitModule(cfg)
+        m.configure_model(state_dict=p)
+        opt, _ = m.configure_optimizers()
+        loss = float(m.training_step(batch))
+        grad = m.full.flat.grad.float().clone()
+        losses = [loss]
+        for _ in range(3):
+            opt[0].step()
+            losses.append(float(m.training_step(batch)))
+        res[fp8] = (loss, grad, losses)
+    l16, g16, _ = res[False]
+    l8, g8, tr8 = res[True]
+    assert abs(l8 - l16) / l16 < 2e-2 and abs(l8 - float(loss_ref)) / float(loss_ref) < 2e-2
+    cos = float((g8 * g16).sum() / (g8.norm() * g16.norm()))
+    print(f"fp8 ladder: loss bf16 {l16:.5f} fp8 {l8:.5f} oracle {float(loss_ref):.5f}; grad cosine {cos:.4f}; fp8 losses {tr8}")
+    assert cos > 0.97
+    assert tr8[-1] < tr8[0]
