@@ -79,6 +79,67 @@ def test_two_rank_gradients_match_single_process(dev, lora):
     assert torch.equal(ret[0]["compute"], ret[1]["compute"])
 
 
+def _worker_full(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.parallel import attach_data_parallel, sync_module_states
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = O.geometry_mini()
+        p = O.round_bf16(O.init_params(g, seed=3))
+        full = O.synthetic_batch(g, 4, seed=4)
+        cfg = dataclasses.replace(_cfg(False), freeze_backbone=False)
+
+        def build():
+            m = VLBLitModule(cfg)
+            m.configure_model(state_dict=p)
+            opt, _ = m.configure_optimizers()
+            return m, opt[0]
+        m, opt = build()
+        st = attach_data_parallel(m, opt)
+        sb = m.sharded_backbone
+        assert sb is not None and sb.active and sb.numel * 2 == m.full.flat.numel and sb.grad.dtype == torch.bfloat16
+        sync_module_states(m)
+        mine = {k: v[rank * 2:rank * 2 + 2] for k, v in full.items()}
+        m.training_step(mine)
+        opt.step()
+        g_dp = sb.gather_full("grad").float()
+        sb.gather_masters()
+        torch.cuda.synchronize()
+        out = {"master": m.full.flat.master.cpu(), "compute": m.full.flat.compute.float().cpu(),
+               "wt_ok": bool(torch.equal(m.backbone.w.layers[1]["wdown_t"], m.backbone.w.layers[1]["wdown"].t()))}
+        if rank == 0:
+            ref, ropt = build()
+            ref.training_step(full)
+            g_ref = ref.full.flat.grad.float().clone()
+            ropt.step()
+            torch.cuda.synchronize()
+            out["cos"] = float((g_dp * g_ref).sum() / (g_dp.norm() * g_ref.norm()))
+            out["perr"] = float((m.full.flat.master - ref.full.flat.master).abs().max())
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_full_finetune_matches_single_process(dev):
+    """configs[4]'s sharding in miniature: the backbone store's bf16 gradients are reduce-scattered per layer chunk,
+    each rank updates its half of every segment (fp32 master / moments only there), bf16 weights are all-gathered and
+    the W^T copies follow; the result tracks the single-process step on the concatenated batch."""
+    import random
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_full, args=(2, 29600 + random.randint(0, 2000), ret), nprocs=2, join=True)
+    assert ret[0]["cos"] > 0.995, ret[0]["cos"]                  # bf16 gradients of two half-batches vs one full batch
+    assert ret[0]["perr"] < 2.5e-3
+    assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
+    assert ret[0]["wt_ok"] and ret[1]["wt_ok"]
+
+
 def test_bench_gpus_2_launches_two_ranks(dev):
     """`python bench.py --gpus 2` with no launcher: two ranks are started (time-sharing this GPU over gloo), rank 0
     prints ONE JSON line with n_gpus 2; asking for more RCCL ranks than GPUs fails instead of running fewer."""
