@@ -26,11 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
-# L2->fabric bytes of ONE gate/up GEMM launch at B=5, measured offline with rocprofv3 --pmc (separate FETCH_SIZE /
-# WRITE_SIZE passes, gfx950 2x read correction): profiles/r01_gemm_gateup_hbm_traffic.csv.  Only valid for that shape.
-GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 2.495e9,     # default (LoRA, packed rows): profiles/r01_gemm_gateup_hbm_traffic_lora.csv
-                        (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows: ..._frozen_w4.csv
-                        (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: ..._traffic.csv
+# L2->fabric bytes of ONE gate/up GEMM call, measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE
+# passes, gfx950 2x read correction; tools/profile_tables.py traffic).  Only valid for that shape.
+GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 2.610e9,     # default (LoRA, packed rows), main launch + split-K tail + reduce: profiles/r02_gemm_gateup_hbm_traffic_lora.csv
+                        (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows, main launch: profiles/r01_gemm_gateup_hbm_traffic_frozen_w4.csv
+                        (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: profiles/r01_gemm_gateup_hbm_traffic.csv
 # algorithmic TFLOP per clip
 TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8, "full": 100.8}
 
@@ -271,7 +271,7 @@ def main():
                          f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_bf16 call", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
-                         "traffic_note": "L2->fabric bytes of the main launch from rocprofv3 PMC passes (profiles/r01_gemm_gateup_hbm_traffic*.csv); "
+                         "traffic_note": "L2->fabric bytes per call from rocprofv3 PMC passes (profiles/r02_gemm_gateup_hbm_traffic_lora.csv; frozen shapes: r01_*); "
                          + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN:.3e} (A | t, W | B, C [M,N] bf16)" if lora else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),

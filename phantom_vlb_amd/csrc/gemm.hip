@@ -1224,7 +1224,11 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   TailPlan p256, p192;
   // (no split-K for the 256-row masked kernel: with 64 accumulator tiles + the mask temporaries the register
   // allocator starts rotating accumulator tuples behind the asm MFMAs; 192-row tiles are fine)
-  const bool use192 = plan_rows(M, N, K + 64, ws_ok, p256, p192, false);
+  bool use192 = plan_rows(M, N, K + 64, ws_ok, p256, p192, false);
+#ifdef VLB_TOOLS
+  if (g_force_tile == 3) use192 = false;      // A/B only: force 256- / 192-row tiles for the masked-pair kernel
+  if (g_force_tile == 4) use192 = true;
+#endif
   const TailPlan& tp = use192 ? p192 : p256;
   const int tm = use192 ? (M + 191) / 192 : (M + 255) / 256;
   const int tiles = tm * tn, rem = tiles % cus;

@@ -1,0 +1,166 @@
+"""Turn rocprofv3 outputs of `bench.py` into the tables committed under profiles/.
+
+  python tools/profile_tables.py stats  <kernel-trace dir> <steps incl. warmup> <out prefix>     # per-kernel table + roofline column
+  python tools/profile_tables.py sq     <pmc dir> <out csv>                                      # SQ counters per kernel
+  python tools/profile_tables.py traffic <fetch dir> <write dir> <out csv>                       # gate/up GEMM call: main + split-K tail + reduce
+
+Algorithmic bytes / flops per call are stated here for the default workload (configs[2], B=3, packed
+rows M=5861, dim 4096, ff 14336, 32/8 heads x 128): the roofline column is (algorithmic work per call) / (avg duration).
+"""
+import csv, glob, os, re, sys
+
+M, E, FF, QD, KD, S, B, HQ = int(os.environ.get("VLB_ROWS", 5861)), 4096, 14336, 4096, 1024, 2048, int(os.environ.get("VLB_CLIPS", 3)), 32
+PEAK_TF, PEAK_TB = 2500.0, 8.0
+# kernel-name regex -> (bound, algorithmic unit per call, value)   [GB for hbm, TFLOP for mfma]
+ATT_FWD = 4.0 * B * HQ * S * S * 128 / 2 / 1e12 * (M / (B * S)) ** 2          # causal, packed rows
+WORK = [
+    (r"rmsnorm_fwd", "hbm", 2 * M * E * 2 / 1e9), (r"rmsnorm_bwd", "hbm", 4 * M * E * 2 / 1e9),
+    (r"swiglu_fwd", "hbm", 3 * M * FF * 2 / 1e9), (r"swiglu_bwd", "hbm", 5 * M * FF * 2 / 1e9),
+    (r"rope_kernel", "hbm", 2 * M * (QD + KD) * 2 / 1e9), (r"attn_fwd_kernel<128", "mfma", ATT_FWD),
+    (r"attn_bwd_dkdv", "mfma", ATT_FWD), (r"attn_bwd_dq", "mfma", 1.5 * ATT_FWD),
+    (r"attn_delta", "hbm", 2 * M * QD * 2 / 1e9), (r"adamw_kernel", "hbm", 50.4e6 * 18 / 1e9), (r"sumsq_kernel", "hbm", 50.4e6 * 4 / 1e9),
+    (r"splice_kernel", "hbm", M * E * 2 / 1e9), (r"head_pool_kernel", "hbm", M * E * 2 / 1e9),
+]
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)[:64]
+
+
+def stats(d, steps, prefix):
+    f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+    rs = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rs)
+    with open(f"profiles/{prefix}_kernel_table.csv", "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps {steps - 2} --warmup 2 --no-cpu-baseline` ({steps} steps in the trace, model init included); "
+                "achieved = algorithmic work per call (tools/profile_tables.py WORK) / avg duration; frac = achieved / (8 TB/s | 2.5 PFLOP/s)\n")
+        o.write("kernel,calls_per_step,avg_us,ms_per_step,pct_of_kernel_time,bound,achieved,unit,frac_of_peak\n")
+        for r in rs:
+            t = float(r["TotalDurationNs"])
+            if t / tot < 0.001:
+                continue
+            name = r["Name"]
+            bound = ach = unit = frac = ""
+            for pat, bd, val in WORK:
+                if re.search(pat, name):
+                    avg_s = float(r["AverageNs"]) * 1e-9
+                    if bd == "hbm":
+                        ach, unit, frac, bound = val / avg_s / 1e3, "TB/s", val / avg_s / 1e3 / PEAK_TB, "hbm"
+                    else:
+                        ach, unit, frac, bound = val / avg_s, "TFLOP/s", val / avg_s / PEAK_TF, "mfma"
+                    ach, frac = f"{ach:.2f}", f"{frac:.3f}"
+                    break
+            if not bound and "gemm" in name:
+                bound = "mfma"
+            o.write(f"\"{short(name)}\",{int(r['Calls']) / steps:.1f},{float(r['AverageNs']) / 1e3:.1f},{t / 1e6 / steps:.2f},{100 * t / tot:.2f},{bound},{ach},{unit},{frac}\n")
+    groups = {"gemm four-wave": 0, "gemm 8-wave": 0, "attention bwd": 0, "attention fwd": 0, "lora skinny": 0, "swiglu": 0, "norms": 0, "other": 0}
+    for r in rs:
+        n, t = r["Name"], float(r["TotalDurationNs"])
+        if "gemm_w4" in n or "gemm_splitk" in n: groups["gemm four-wave"] += t
+        elif "gemm_" in n: groups["gemm 8-wave"] += t
+        elif "attn_bwd" in n or "attn_delta" in n or "attn_dkdv" in n: groups["attention bwd"] += t
+        elif "attn_fwd" in n: groups["attention fwd"] += t
+        elif "lora_" in n or "wgrad" in n or "transpose16" in n: groups["lora skinny"] += t
+        elif "swiglu" in n: groups["swiglu"] += t
+        elif "norm" in n: groups["norms"] += t
+        else: groups["other"] += t
+    with open(f"profiles/{prefix}_kernel_groups.txt", "w") as o:
+        o.write(f"kernel time {tot / 1e6 / steps:.1f} ms/step over {steps} traced steps (incl. 2 warm-up steps and model init)\n")
+        for k, v in groups.items():
+            o.write(f"  {k:16s} {100 * v / tot:5.1f} %  {v / 1e6 / steps:6.1f} ms/step\n")
+    print(open(f"profiles/{prefix}_kernel_groups.txt").read())
+    # gate/up call from the trace
+    t = max(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    tr = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
+    w4 = [r for r in tr if re.search(r"gemm_w4_kernel<8, 0, 8, false, false>", r["Kernel_Name"])]
+    if not w4:
+        return
+    key = "Grid_Size_X" if "Grid_Size_X" in w4[0] else "Grid_Size"
+    gmax = max(int(r[key]) for r in w4)
+    idx = {id(r): i for i, r in enumerate(tr)}
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    main_l = [r for r in w4 if int(r[key]) == gmax]
+    dm, tails = [dur(r) for r in main_l], []
+    for r in main_l:
+        t_us, j = 0.0, idx[id(r)] + 1
+        while j < len(tr) and ("gemm_w4_kernel<8, 0, 8, false, true>" in tr[j]["Kernel_Name"] or "gemm_splitk_reduce" in tr[j]["Kernel_Name"]
+                               or "gemm_w4_kernel<4" in tr[j]["Kernel_Name"]):
+            t_us += dur(tr[j]); j += 1
+        tails.append(t_us)
+    call = sum(dm) / len(dm) + sum(tails) / len(tails)
+    with open(f"profiles/{prefix}_gateup_gemm_launches.csv", "w") as o:
+        o.write("# gate/up GEMM call = gemm_w4_kernel<8,0,8,false,false> main launch (largest grid) + the split-K launches of its partial last wave "
+                "(gemm_w4_kernel<8,0,8,false,true> + gemm_splitk_reduce_kernel); us, from the kernel trace\n")
+        o.write(f"main_launches,{len(dm)},avg_us,{sum(dm) / len(dm):.2f},min_us,{min(dm):.2f},max_us,{max(dm):.2f}\n")
+        o.write(f"tail_launches,{len(tails)},avg_us,{sum(tails) / len(tails):.2f}\n")
+        o.write(f"call_avg_us,{call:.2f},tflops,{2.0 * M * 2 * FF * E / call / 1e6:.1f},frac_of_2500,{2.0 * M * 2 * FF * E / call / 1e6 / PEAK_TF:.4f}\n")
+    print(open(f"profiles/{prefix}_gateup_gemm_launches.csv").read())
+
+
+def sq(d, out):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        a = acc.setdefault(k, {})
+        c = a.setdefault(r["Counter_Name"], [0.0, 0])
+        c[0] += float(r["Counter_Value"]); c[1] += 1
+    cols = ["SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --pmc " + " ".join(cols) + " on `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (default LoRA workload); per-kernel means over dispatches\n")
+        o.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / 4 / 8 (SQ_BUSY_CYCLES accumulates per shader engine, 32 on the chip with 32 SIMDs each; MFMA busy per SIMD): matrix-pipe busy share of SIMD cycles\n")
+        o.write("# lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES\n")
+        o.write("kernel,dispatches," + ",".join(cols) + ",mfma_busy_frac,lds_conflict_frac,wait_inst_frac,wait_any_frac\n")
+        rows = []
+        for k, a in acc.items():
+            m = {c: (a[c][0] / a[c][1] if c in a else 0.0) for c in cols}
+            n = max(v[1] for v in a.values())
+            busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_BUSY_CYCLES"] / 32 if m["SQ_BUSY_CYCLES"] else 0
+            conf = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if m["SQ_LDS_IDX_ACTIVE"] else 0
+            wi = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else 0
+            wa = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m["SQ_WAVE_CYCLES"] else 0
+            rows.append((m["SQ_BUSY_CYCLES"] * n, f"\"{k}\",{n}," + ",".join(f"{m[c]:.0f}" for c in cols) + f",{busy:.3f},{conf:.3f},{wi:.3f},{wa:.3f}\n"))
+        for _, line in sorted(rows, reverse=True)[:40]:
+            o.write(line)
+    print(open(out).read()[:3000])
+
+
+def traffic(dfetch, dwrite, out):
+    res = {}
+    for d, c in ((dfetch, "FETCH_SIZE"), (dwrite, "WRITE_SIZE")):
+        f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+        rs = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
+        rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+        main = [r for r in rs if "gemm_w4_kernel<8, 0, 8, false, false>" in r["Kernel_Name"]]
+        grid = max(int(r["Grid_Size"]) for r in main)
+        pos = {r["Dispatch_Id"]: i for i, r in enumerate(rs)}
+        mains, tails = [], []
+        for r in main:
+            if int(r["Grid_Size"]) != grid:
+                continue
+            mains.append(float(r["Counter_Value"]))
+            t, j = 0.0, pos[r["Dispatch_Id"]] + 1
+            while j < len(rs) and ("gemm_w4_kernel<8, 0, 8, false, true>" in rs[j]["Kernel_Name"] or "gemm_splitk_reduce" in rs[j]["Kernel_Name"]):
+                t += float(rs[j]["Counter_Value"]); j += 1
+            tails.append(t)
+        res[c] = (grid, len(mains), sum(mains) / len(mains), sum(tails) / len(tails))
+    fm, ft = res["FETCH_SIZE"][2], res["FETCH_SIZE"][3]
+    wm, wt = res["WRITE_SIZE"][2], res["WRITE_SIZE"][3]
+    total = (2 * (fm + ft) + wm + wt) * 1024
+    alg = 2.0 * (M * (E + 64) + 2 * FF * (E + 64)) + 2.0 * M * 2 * FF
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (default LoRA workload, packed rows)\n")
+        o.write("# one gate/up GEMM CALL = main gemm_w4_kernel launch (10 full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
+        o.write("# gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
+        o.write("counter,main_grid_threads,calls,main_mean_kb,tail_mean_kb\n")
+        for c, (g, n, a, b) in res.items():
+            o.write(f"{c},{g},{n},{a:.1f},{b:.1f}\n")
+        o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} (A|t + W|B + C [M,N] bf16); ratio {total / alg:.2f}\n")
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    {"stats": lambda: stats(sys.argv[2], int(sys.argv[3]), sys.argv[4]), "sq": lambda: sq(sys.argv[2], sys.argv[3]),
+     "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4])}[sys.argv[1]]()
