@@ -332,7 +332,7 @@ int vlb_adamw_step_g16(float* master, void* param_bf16, const void* grad_bf16, f
                        void* stream);
 /* STC connector backward pieces: depthwise 3x3 weight gradient [9,C]; squeeze-excite gate-logit and input gradients;
  * inverse of vlb_im2col3d_k2s2p1 (every input element sits in exactly one 2x2x2 window) */
-int64_t vlb_dwconv3x3_bwd_w_ws_floats(int N, int C);
+int64_t vlb_dwconv3x3_bwd_w_ws_floats(int N, int H, int C);
 int vlb_dwconv3x3_bwd_w(const void* x, const void* dy, void* dw9_bf16, float* ws, int N, int H, int W, int C, void* stream);
 int vlb_se_bwd_gate(const void* x, const void* dy, const void* s, void* ds, int N, int HW, int C, void* stream);
 int vlb_se_bwd_x(const void* dy, const void* s, const void* dpool, void* dx, int N, int HW, int C, void* stream);

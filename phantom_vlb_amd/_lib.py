@@ -79,7 +79,7 @@ SIGNATURES = {
     "vlb_embed_grad": [P, I, P, P, P, I, P, I, P],
     "vlb_grad_sumsq_bf16": [P, L, P, P, P],
     "vlb_adamw_step_g16": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
-    "vlb_dwconv3x3_bwd_w_ws_floats": [I, I],
+    "vlb_dwconv3x3_bwd_w_ws_floats": [I, I, I],
     "vlb_dwconv3x3_bwd_w": [P, P, P, P, I, I, I, I, P],
     "vlb_se_bwd_gate": [P, P, P, P, I, I, I, P],
     "vlb_se_bwd_x": [P, P, P, P, I, I, I, P],

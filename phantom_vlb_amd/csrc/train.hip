@@ -103,15 +103,26 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_partial_kernel(const bf16* __r
   for (int c = threadIdx.x; c < dim; c += 256)
     part[(int64_t)blockIdx.x * dim + c] = red[c] + red[dim + c] + red[2 * dim + c] + red[3 * dim + c];
 }
-// out[c] = sum_b part[b][c] (b ascending); bf16 or fp32 output, optional accumulate
+// out[c] = sum_b part[b][c]: a block owns 32 columns; 8 row groups of threads each sum the partials b = g, g+8, ...
+// (ascending), the 8 group sums are added in a fixed order: deterministic, and nb/8 dependent loads per thread
+// instead of nb.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int nb, int dim, bf16* __restrict__ out_bf16,
                                                              float* __restrict__ out_f32) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= dim) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * dim + c];
-  if (out_bf16) out_bf16[c] = (bf16)s;
-  if (out_f32) out_f32[c] = s;
+  if (c < dim)
+    for (int b = grp; b < nb; b += 8) s += part[(int64_t)b * dim + c];
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < dim) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][cl];
+    if (out_bf16) out_bf16[c] = (bf16)t;
+    if (out_f32) out_f32[c] = t;
+  }
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients) / two-column variants
@@ -169,40 +180,47 @@ __global__ __launch_bounds__(256) void sumsq_final_b_kernel(const float* __restr
   s = block_sum(s, red);
   if (threadIdx.x == 0) out[0] += s;
 }
-// 8 parameters per thread: 16-byte bf16 gradient / bf16 copy accesses, 2 x 16-byte fp32 accesses per state buffer
+// 4 consecutive parameters per thread: every fp32 state access is one fully coalesced 16-byte lane access (1 KiB per
+// wave instruction), the bf16 gradient / copy 8 bytes per lane; two independent chunks per loop trip keep 14 loads in
+// flight per thread.
+__device__ __forceinline__ void adamw4(float* __restrict__ p, bf16* __restrict__ pb, const bf16* __restrict__ g, float* __restrict__ m,
+                                       float* __restrict__ v, int64_t i4, float clip, float lr, float b1, float b2, float eps, float wd,
+                                       float bc1, float bc2_sqrt, f32x4 pv, f32x4 mv, f32x4 vv, bf16x4 gv) {
+  bf16x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gi = (float)gv[k] * clip;
+    float pi = pv[k] * (1.f - lr * wd);
+    const float mi = b1 * mv[k] + (1.f - b1) * gi;
+    const float vi = b2 * vv[k] + (1.f - b2) * gi * gi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    pv[k] = pi; mv[k] = mi; vv[k] = vi; o[k] = (bf16)pi;
+  }
+  *reinterpret_cast<f32x4*>(p + i4 * 4) = pv;
+  *reinterpret_cast<f32x4*>(m + i4 * 4) = mv;
+  *reinterpret_cast<f32x4*>(v + i4 * 4) = vv;
+  if (pb) *reinterpret_cast<bf16x4*>(pb + i4 * 4) = o;
+}
 __global__ __launch_bounds__(256) void adamw_g16_kernel(float* __restrict__ p, bf16* __restrict__ pb, const bf16* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v, int64_t n8, float lr, float b1,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n4, float lr, float b1,
                                                         float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                                         const float* __restrict__ sumsq, float max_norm) {
   float clip = 1.f;
   if (max_norm > 0.f && sumsq) clip = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-    float gv[8]; ld8(g + i * 8, gv);
-    f32x4 pv[2], mv[2], vv[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      pv[h] = *reinterpret_cast<const f32x4*>(p + i * 8 + 4 * h);
-      mv[h] = *reinterpret_cast<const f32x4*>(m + i * 8 + 4 * h);
-      vv[h] = *reinterpret_cast<const f32x4*>(v + i * 8 + 4 * h);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const int64_t j = i + stride;
+    const bool two = j < n4;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p + i * 4), m0 = *reinterpret_cast<const f32x4*>(m + i * 4),
+                v0 = *reinterpret_cast<const f32x4*>(v + i * 4);
+    const bf16x4 g0 = *reinterpret_cast<const bf16x4*>(g + i * 4);
+    f32x4 p1{}, m1{}, v1{}; bf16x4 g1{};
+    if (two) {
+      p1 = *reinterpret_cast<const f32x4*>(p + j * 4); m1 = *reinterpret_cast<const f32x4*>(m + j * 4);
+      v1 = *reinterpret_cast<const f32x4*>(v + j * 4); g1 = *reinterpret_cast<const bf16x4*>(g + j * 4);
     }
-    float o[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float gi = gv[k] * clip;
-      float pi = pv[k >> 2][k & 3] * (1.f - lr * wd);
-      const float mi = b1 * mv[k >> 2][k & 3] + (1.f - b1) * gi;
-      const float vi = b2 * vv[k >> 2][k & 3] + (1.f - b2) * gi * gi;
-      pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
-      pv[k >> 2][k & 3] = pi; mv[k >> 2][k & 3] = mi; vv[k >> 2][k & 3] = vi;
-      o[k] = pi;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<f32x4*>(p + i * 8 + 4 * h) = pv[h];
-      *reinterpret_cast<f32x4*>(m + i * 8 + 4 * h) = mv[h];
-      *reinterpret_cast<f32x4*>(v + i * 8 + 4 * h) = vv[h];
-    }
-    if (pb) st8(pb + i * 8, o);
+    adamw4(p, pb, g, m, v, i, clip, lr, b1, b2, eps, wd, bc1, bc2_sqrt, p0, m0, v0, g0);
+    if (two) adamw4(p, pb, g, m, v, j, clip, lr, b1, b2, eps, wd, bc1, bc2_sqrt, p1, m1, v1, g1);
   }
 }
 
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(256) void dwconv_dw_partial_kernel(const bf16* __re
                                                                 int H, int W, int C) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
   if (c >= C) return;
-  const int n = blockIdx.y;
+  const int n = blockIdx.y / H, h = blockIdx.y % H;       // one block row per (image, image row): N*H partial slabs
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -349,22 +367,21 @@ __global__ __launch_bounds__(256) void dwconv_dw_partial_kernel(const bf16* __re
     for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
   const bf16* xn = x + (int64_t)n * H * W * C;
   const bf16* gn = dy + (int64_t)n * H * W * C;
-  for (int h = 0; h < H; ++h)
-    for (int w = 0; w < W; ++w) {
-      float g[8]; ld8(gn + ((int64_t)h * W + w) * C + c, g);
+  for (int w = 0; w < W; ++w) {
+    float g[8]; ld8(gn + ((int64_t)h * W + w) * C + c, g);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-        float v[8]; ld8(xn + ((int64_t)hh * W + ww) * C + c, v);
+    for (int t = 0; t < 9; ++t) {
+      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      float v[8]; ld8(xn + ((int64_t)hh * W + ww) * C + c, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[t][i] += g[i] * v[i];
-      }
+      for (int i = 0; i < 8; ++i) acc[t][i] += g[i] * v[i];
     }
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part[((int64_t)n * 9 + t) * C + c + i] = acc[t][i];
+    for (int i = 0; i < 8; ++i) part[((int64_t)blockIdx.y * 9 + t) * C + c + i] = acc[t][i];
 }
 
 // ---------------------------------------------------------------- squeeze-excite backward
@@ -450,7 +467,7 @@ extern "C" int vlb_rmsnorm_bwd_dw(const void* x, const void* dy, void* dw_bf16, 
   if (dim <= 512) VLB_RDW(1); else if (dim <= 1024) VLB_RDW(2); else if (dim <= 2048) VLB_RDW(4); else VLB_RDW(8);
 #undef VLB_RDW
   VLB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, ws, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, ws, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -473,8 +490,8 @@ extern "C" int vlb_layernorm_bwd(const void* x, const void* w, const void* b, co
   if (dim <= 512) VLB_LNB(1); else if (dim <= 1024) VLB_LNB(2); else if (dim <= 2048) VLB_LNB(4); else VLB_LNB(8);
 #undef VLB_LNB
   VLB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, pg, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, pb, nb, dim, (bf16*)db_bf16, (float*)nullptr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, pg, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, pb, nb, dim, (bf16*)db_bf16, (float*)nullptr);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -504,7 +521,7 @@ extern "C" int vlb_colsum(const void* x, int ld, void* out_bf16, float* ws, int 
   const int rpb = norm_rows_per_block(rows), nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((dim / 8 + 255) / 256, nb), dim3(256), 0, st, (const bf16*)x, ld, ws, rows, dim, rpb);
   VLB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 255) / 256), dim3(256), 0, st, ws, nb, dim, (bf16*)out_bf16, (float*)nullptr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, ws, nb, dim, (bf16*)out_bf16, (float*)nullptr);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -535,23 +552,25 @@ extern "C" int vlb_adamw_step_g16(float* master, void* param_bf16, const void* g
                                   float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq, float max_norm,
                                   void* stream) {
   VLB_REQUIRE(n > 0 && n % 8 == 0 && master && grad_bf16 && m && v && step >= 1, "adamw_g16: n must be a positive multiple of 8");
+  VLB_REQUIRE((((uintptr_t)master | (uintptr_t)m | (uintptr_t)v) % 16) == 0 && (((uintptr_t)grad_bf16 | (uintptr_t)param_bf16) % 8) == 0,
+              "adamw_g16: buffers must be 16-byte (fp32) / 8-byte (bf16) aligned");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  const int64_t n8 = n / 8;
-  int64_t nb = (n8 + 255) / 256; if (nb > 16384) nb = 16384;
+  const int64_t n4 = n / 4;
+  int64_t nb = (n4 + 511) / 512; if (nb > 32768) nb = 32768;
   hipLaunchKernelGGL(adamw_g16_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), master, (bf16*)param_bf16, (const bf16*)grad_bf16,
-                     m, v, n8, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, sumsq, max_norm);
+                     m, v, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, sumsq, max_norm);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
 
-extern "C" int64_t vlb_dwconv3x3_bwd_w_ws_floats(int N, int C) { return (int64_t)N * 9 * C; }
+extern "C" int64_t vlb_dwconv3x3_bwd_w_ws_floats(int N, int H, int C) { return (int64_t)N * H * 9 * C; }
 extern "C" int vlb_dwconv3x3_bwd_w(const void* x, const void* dy, void* dw9_bf16, float* ws, int N, int H, int W, int C, void* stream) {
   VLB_REQUIRE(x && dy && dw9_bf16 && ws && N > 0 && H > 0 && W > 0 && C % 8 == 0, "dwconv3x3_bwd_w: bad args");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(dwconv_dw_partial_kernel, dim3((C / 8 + 255) / 256, N), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, ws, H, W, C);
+  hipLaunchKernelGGL(dwconv_dw_partial_kernel, dim3((C / 8 + 255) / 256, N * H), dim3(256), 0, st, (const bf16*)x, (const bf16*)dy, ws, H, W, C);
   VLB_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, ws, N, 9 * C, (bf16*)dw9_bf16, (float*)nullptr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((9 * C + 31) / 32), dim3(256), 0, st, ws, N * H, 9 * C, (bf16*)dw9_bf16, (float*)nullptr);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

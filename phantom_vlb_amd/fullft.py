@@ -142,18 +142,26 @@ class FullFineTune:
         yield "ro0", self.w.ro0[0]
         yield "ro2", self.w.ro2[0]
 
+    @staticmethod
+    def _wt(w, w_t):
+        """w_t[C, R] = w[R, C]^T with 16-byte accesses on both sides (R % 8 == 0 for every trained matrix)."""
+        R, C = w.shape
+        if R % 8 == 0:
+            ops.transpose_pad(w, w_t, R)
+        else:
+            check(lib.vlb_transpose_bf16(w.data_ptr(), w_t.data_ptr(), R, C, _stream()), "vlb_transpose_bf16")
+
     def refresh_transposed(self, decoder=True):
         """After an optimiser step: W^T copies for the dgrad GEMMs (two passes over the trained weights)."""
         for name, wt in self._conn_linears():
             R, C = wt.shape
             if name not in self.conn_t:
                 self.conn_t[name] = torch.empty(C, R, dtype=BF16, device=self.dev)
-            check(lib.vlb_transpose_bf16(wt.data_ptr(), self.conn_t[name].data_ptr(), R, C, _stream()), "vlb_transpose_bf16")
+            self._wt(wt, self.conn_t[name])
         if decoder:
             for lw in self.w.layers:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
-                    R, C = lw[k].shape
-                    check(lib.vlb_transpose_bf16(lw[k].data_ptr(), lw[k + "_t"].data_ptr(), R, C, _stream()), "vlb_transpose_bf16")
+                    self._wt(lw[k], lw[k + "_t"])
         if self.fp8:
             for li, lw in enumerate(self.w.layers):
                 for k in ("wqkv", "wo", "wgu", "wdown", "wqkv_t", "wo_t", "wgu_t", "wdown_t"):

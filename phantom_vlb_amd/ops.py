@@ -461,7 +461,7 @@ def embed_grad(d_embeds, tok, beg, rows, out, D):
 
 
 def dwconv3x3_bwd_w(x, dy, N, H, W, C, out):
-    ws = _ws(lib.vlb_dwconv3x3_bwd_w_ws_floats(N, C), x.device, "dw")
+    ws = _ws(lib.vlb_dwconv3x3_bwd_w_ws_floats(N, H, C), x.device, "dw")
     check(lib.vlb_dwconv3x3_bwd_w(_dev(x).data_ptr(), dy.data_ptr(), out.data_ptr(), ws.data_ptr(), N, H, W, C, _stream()),
           "vlb_dwconv3x3_bwd_w")
     return out
