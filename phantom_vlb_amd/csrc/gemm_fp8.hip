@@ -4,7 +4,7 @@
 // the unscaled fp8 MFMAs run at the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  BASELINE configs[4] asks for
 // fp8 MFMA GEMMs on the full fine-tune's linears; vlb_quantize_mxfp8 produces the operands from bf16.
 //
-// Kernel: 256x256 output tile, K step 128 (= one MFMA K), 512 threads = 2(M) x 4(N) waves of 128x64; operands go
+// Kernel: 256x256 output tile, K step 128 (= one MFMA K), 256 threads = 2(M) x 2(N) waves of 128x128; operands go
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double-buffered image of 128-byte rows whose 16-byte
 // chunks are XOR-swizzled on the SOURCE address (chunk c of row r at slot c ^ ((r>>1)&7)).  Operand layout of the
 // instruction, measured with exact data (tools/probe_mfma_scale.py): lane l = (row l&15, group g = l>>4) holds
@@ -12,7 +12,7 @@
 // and 4+g of the row), while the E8M0 scale it supplies is the one of 32-element block g (k = 32g..32g+31) of its
 // row; both operands' scales are bytes of ONE register (see the K loop).  MFMA roles are swapped like in the
 // bf16 kernel (MFMA rows = output columns) so a lane owns 4 consecutive n of one output row: 8-byte stores.
-// Scales: one byte per (row, 32-element K block), read straight from global (L2-resident) one K-tile ahead.
+// Scales: one byte per (row, 32-element K block); the u32 of a row's four blocks per K-tile rides the same LDS-DMA ring.
 #include "common.hpp"
 
 namespace {
@@ -32,11 +32,26 @@ __device__ __forceinline__ void glds16f(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(Fp8Args p) {
+__device__ __forceinline__ void glds4f(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 4, 0, 0);
+}
+
+// 256 threads = 2(M) x 2(N) waves, one per SIMD with the full 512-register budget; wave block 128 x 128 = 64
+// accumulator tiles.  Per K-tile (128 bytes of K per row) a wave reads all its fragments (32 ds_read_b128) and scale
+// words into registers, the workgroup passes a barrier, and the stage just read is immediately refilled with tile
+// kt+2 by LDS-DMA while the 64 MFMAs of tile kt run - every DMA has one whole iteration plus an MFMA phase to land
+// (counted vmcnt, never 0 inside the loop).  Scales travel through LDS as well (global_load_lds_dword, one u32 = the
+// four block scales of a row per K-tile), so the loop holds no register-destination global load for the compiler to
+// drain the DMA queue on.
+constexpr int F_STAGE = 2 * 256 * FROW + 2 * 256 * 4;      // A image + W image + A scale words + W scale words = 66 KB
+constexpr int F_VM_PER_TILE = 18;                           // per wave: 8 + 8 x 1 KiB pieces, 1 + 1 scale pieces
+
+__global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = 256 * FROW, STAGE = 2 * A_BYTES;       // 64 KB per stage, 2 stages
+  constexpr int A_BYTES = 256 * FROW;
+  constexpr int SA_OFF = 2 * A_BYTES, SW_OFF = SA_OFF + 256 * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave >> 1, wn = wave & 1;
   // ---- tile order: XCD-contiguous runs (blocks b and b+8 share an XCD), bands of 4 row tiles
   const int ntiles = p.tiles_m * p.tiles_n;
   int t;
@@ -50,91 +65,82 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(Fp8Args p) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = p.K / FBK;
 
-  // ---- LDS-DMA: a wave instruction writes 1 KiB = 8 rows x 128 B; thread -> (row, slot); source chunk = slot ^ swz(row)
-  // per K-tile and operand: 256 rows = 32 pieces; 8 waves x 4 pieces
-  const char* srcA[4]; const char* srcW[4];
-  int dstoff[4];
+  // ---- LDS-DMA sources.  Data: a wave instruction writes 1 KiB = 8 rows x 128 B; lane -> (row, slot); source chunk =
+  // slot ^ swz(row).  Wave w owns rows 64w..64w+63 of both operands (8 pieces each).  Scales: lane l of wave w moves
+  // the u32 of row 64w + l.
+  const char* srcA[8]; const char* srcW[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int piece = wave * 4 + j;
-    const int r = piece * 8 + (lane >> 3), s = lane & 7;
+  for (int j = 0; j < 8; ++j) {
+    const int r = wave * 64 + j * 8 + (lane >> 3), s = lane & 7;
     const int c = s ^ ((r >> 1) & 7);
     srcA[j] = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * p.lda + c * 16;
     srcW[j] = reinterpret_cast<const char*>(p.W) + (int64_t)(n0 + r) * p.ldw + c * 16;
-    dstoff[j] = piece * 1024;                       // + lane*16 is added by the hardware
   }
+  const char* srcSA = reinterpret_cast<const char*>(p.sA) + (int64_t)min(m0 + wave * 64 + lane, p.M - 1) * p.ldsa;
+  const char* srcSW = reinterpret_cast<const char*>(p.sW) + (int64_t)(n0 + wave * 64 + lane) * p.ldsw;
   auto stage = [&](int st, int kt) {
-    char* base = smem + st * STAGE;
+    char* base = smem + st * F_STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      glds16f(srcA[j] + (int64_t)kt * FBK, base + dstoff[j]);
-      glds16f(srcW[j] + (int64_t)kt * FBK, base + A_BYTES + dstoff[j]);
+    for (int j = 0; j < 8; ++j) {
+      glds16f(srcA[j] + (int64_t)kt * FBK, base + (wave * 8 + j) * 1024);
+      glds16f(srcW[j] + (int64_t)kt * FBK, base + A_BYTES + (wave * 8 + j) * 1024);
     }
+    glds4f(srcSA + kt * 4, base + SA_OFF + wave * 256);
+    glds4f(srcSW + kt * 4, base + SW_OFF + wave * 256);
   };
-  // ---- fragments and scales
   const int fr = lane & 15, g = lane >> 4;
-  const uint8_t* sa_ptr[8]; const uint8_t* sw_ptr[4];
+  f32x4 acc[8][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sa_ptr[i] = p.sA + (int64_t)min(m0 + wm * 128 + i * 16 + fr, p.M - 1) * p.ldsa + g;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) sw_ptr[j] = p.sW + (int64_t)(n0 + wn * 64 + j * 16 + fr) * p.ldsw + g;
-  int sa_cur[8], sw_cur[4], sa_nxt[8], sw_nxt[4];
-  auto load_scales = [&](int kt, int (&sa)[8], int (&sw)[4]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sa[i] = sa_ptr[i][kt * 4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sw[j] = sw_ptr[j][kt * 4];
-  };
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage(0, 0);
-  load_scales(0, sa_cur, sw_cur);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (nk > 1) stage(1, 1);
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) { stage((kt + 1) & 1, kt + 1); load_scales(kt + 1, sa_nxt, sw_nxt); }
-    const char* sb = smem + (kt & 1) * STAGE;
-    i32x8 wf[4];
+    const char* sb = smem + (kt & 1) * F_STAGE;
+    i32x8 wf[8], af[8];
+    int swb[8], sab[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = wn * 64 + j * 16 + fr;
+    for (int j = 0; j < 8; ++j) {
+      const int r = wn * 128 + j * 16 + fr;
       const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, g));
       const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, 4 + g));
       wf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      swb[j] = *reinterpret_cast<const int*>(sb + SW_OFF + r * 4);
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      i32x8 af[4];
+    for (int i = 0; i < 8; ++i) {
+      const int r = wm * 128 + i * 16 + fr;
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + f_off(r, g));
+      const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + f_off(r, 4 + g));
+      af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      sab[i] = *reinterpret_cast<const int*>(sb + SA_OFF + r * 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                          // every wave holds tile kt in registers: its stage is free
+    if (kt + 2 < nk) stage(kt & 1, kt + 2);
+    // Both E8M0 scales travel in ONE register: byte 0 = the MFMA-A operand's (the W rows), byte 1 = the MFMA-B
+    // operand's (the activation rows), selected by op_sel 0 / 1.  Measured on gfx950 with ROCm 7.2
+    // (tools/probe_mfma_scale.py): the instruction takes both scale bytes from the register in the scale_b position
+    // and ignores the scale_a register; passing the same packed register in both positions is right under either reading.
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const int r = wm * 128 + (half * 4 + ii) * 16 + fr;
-        const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + f_off(r, g));
-        const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + f_off(r, 4 + g));
-        af[ii] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int j = 0; j < 8; ++j) swb[j] = (swb[j] >> (8 * g)) & 0xff;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sab[i] = ((sab[i] >> (8 * g)) & 0xff) << 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int sc = swb[j] | sab[i];
+        acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
       }
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // Both E8M0 scales travel in ONE register: byte 0 = the MFMA-A operand's (the W rows), byte 1 = the MFMA-B
-          // operand's (the activation rows), selected by op_sel 0 / 1.  Measured on gfx950 with ROCm 7.2
-          // (tools/probe_mfma_scale.py): the instruction takes both scale bytes from the register in the scale_b
-          // position and ignores the scale_a register; passing the same packed register in both positions is right
-          // under either reading.
-          const int sc = sw_cur[j] | (sa_cur[half * 4 + ii] << 8);
-          acc[j][half * 4 + ii] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[ii], acc[j][half * 4 + ii], 0, 0, 0, sc, 1, sc);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile kt+1 (and its scales) landed
-    __syncthreads();                                        // everyone is done reading stage kt&1
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sa_cur[i] = sa_nxt[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sw_cur[j] = sw_nxt[j];
+    // tile kt+1 must have landed before the next iteration reads it: everything older than tile kt+2's 18 pieces
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
   // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}
 #pragma unroll
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(Fp8Args p) {
     const int m = m0 + wm * 128 + i * 16 + fr;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + wn * 128 + j * 16 + 4 * g;
       f32x4 v = acc[j][i];
       if (p.residual) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
@@ -258,16 +264,17 @@ extern "C" int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa,
                               int ldc, int M, int N, int K, const void* residual, int ldr, void* stream) {
   VLB_REQUIRE(Aq && sA && Wq && sW && C, "gemm_mxfp8: null operand");
   VLB_REQUIRE(M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 128 == 0, "gemm_mxfp8: needs N %% 256 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
-  VLB_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldsa >= K / 32 && ldsw >= K / 32 && ldc % 4 == 0 && ldc >= N,
-              "gemm_mxfp8: bad leading dimensions");
-  VLB_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq) % 16) == 0 && ((uintptr_t)C % 8) == 0, "gemm_mxfp8: misaligned operand");
+  VLB_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldsa >= K / 32 && ldsw >= K / 32 && ldsa % 4 == 0 && ldsw % 4 == 0 &&
+                  ldc % 4 == 0 && ldc >= N, "gemm_mxfp8: bad leading dimensions (scale rows must be 4-byte multiples)");
+  VLB_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq) % 16) == 0 && ((uintptr_t)C % 8) == 0 && (((uintptr_t)sA | (uintptr_t)sW) % 4) == 0,
+              "gemm_mxfp8: misaligned operand");
   if (residual) VLB_REQUIRE(ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0, "gemm_mxfp8: bad residual");
   Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
             M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + 255) / 256, N / 256};
-  constexpr int LDS = 2 * 2 * 256 * 128;
+  constexpr int LDS = 2 * F_STAGE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
-  hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(512), LDS, as_stream(stream), a);
+  hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, as_stream(stream), a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
