@@ -210,13 +210,14 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16* __restr
   }
   s[(int64_t)r * lds_ + kb] = (uint8_t)(E + 127);
   const float inv = exp2f((float)-E);
+  // v_cvt_pk_fp8_f32: two floats -> two OCP e4m3 bytes, round-to-nearest-even (the scaled block never exceeds 448)
   uint32_t w[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    uint32_t pk = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pk |= (uint32_t)f32_to_e4m3(v[c * 4 + k] * inv) << (8 * k);
-    w[c] = pk;
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c * 4] * inv, v[c * 4 + 1] * inv, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c * 4 + 2] * inv, v[c * 4 + 3] * inv, pk, true);
+    w[c] = (uint32_t)pk;
   }
   u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)r * ldq + kb * 32);
   qp[0] = u32x4{w[0], w[1], w[2], w[3]};
