@@ -251,7 +251,7 @@ def main():
             "config": {"workload": {"frozen": "configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16",
                                     "lora": "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16",
                                     "full": f"configs[4] model side: VideoLLaMA2-7B full-parameter fine-tune (all but the vision tower), "
-                                            f"{num_target}-voxel head, " + ("MX-fp8 decoder forward/dgrad GEMMs, bf16 wgrad" if a.fp8 else "bf16 GEMMs")}[a.workload]
+                                            f"{num_target}-voxel head, " + ("MX-fp8 decoder forward / dgrad / wgrad GEMMs" if a.fp8 else "bf16 GEMMs")}[a.workload]
                        if a.geometry == "7b" else "configs[0]-shaped mini model (debug)",
                        "clips_per_gpu": B, "global_batch": world * B, "seq_len": g.max_len, "frames": g.num_frames,
                        "num_target": cfg.num_target, "weights": "random-init",

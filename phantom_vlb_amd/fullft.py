@@ -120,7 +120,8 @@ class FullFineTune:
     def __init__(self, g: Geometry, backbone, device, fp8_gemm: bool = False):
         """``fp8_gemm``: run the decoder's forward and dgrad GEMMs on the block-scaled fp8 MFMA path (MX e4m3 with
         E8M0 scales per 32 K elements, ``vlb_gemm_mxfp8``): activations are quantised per use, the weights (and their
-        transposes) once per optimiser step; weight gradients, attention, norms and the optimiser stay as they are."""
+        transposes) once per optimiser step, the decoder's weight gradients quantise their transposed operands along the
+        token axis; attention, norms, the connector and the optimiser stay as they are."""
         self.g, self.bb, self.w, self.dev = g, backbone, backbone.w, device
         self.fp8 = bool(fp8_gemm)
         self.wq = {}                          # (layer, key) -> (uint8 e4m3 weights, uint8 scales)
@@ -184,19 +185,38 @@ class FullFineTune:
             buf = self._tb[key] = torch.empty(r0, c0, dtype=BF16, device=self.dev)
         return buf
 
-    def _transposed(self, x, tag):
-        """x [M, C] -> view [C, Mp] of x^T with the token axis zero-padded to a multiple of 64."""
+    def _transposed(self, x, tag, gran=64):
+        """x [M, C] -> view [C, Mp] of x^T with the token axis zero-padded to a multiple of `gran` (the GEMM's K granule)."""
         M, C = x.shape
-        Mp = _up(M, 64)
+        Mp = _up(M, gran)
         buf = self._tbuf(tag, C, Mp)
         ops.transpose_pad(x, buf, Mp)
         return buf[:C, :Mp]
 
-    def wgrad(self, dy, x, out, dyT=None, xT=None):
-        """out[N, K] (bf16 view into the flat gradient buffer) = dy[M,N]^T . x[M,K]."""
+    def wgrad(self, dy, x, out, dyT=None, xT=None, fp8=False):
+        """out[N, K] (bf16 view into the flat gradient buffer) = dy[M,N]^T . x[M,K].  fp8: both transposed operands are
+        quantised along the token axis (MX blocks of 32 tokens) and the product runs on the MX-fp8 MFMA GEMM."""
+        if fp8 and out.shape[1] % 256 == 0:
+            dyT, xT = self._transposed(dy, "dyT", 128), self._transposed(x, "xT", 128)
+            N, Mp = dyT.shape
+            K = xT.shape[0]
+            qa, sa = self._qbuf("dyTq", N, Mp)
+            qb, sb = self._qbuf("xTq", K, Mp)
+            ops.quantize_mxfp8(dyT, qa, sa)
+            ops.quantize_mxfp8(xT, qb, sb)
+            ops.gemm_mxfp8(qa, sa, qb, sb, out=out)
+            return
         dyT = self._transposed(dy, "dyT") if dyT is None else dyT
         xT = self._transposed(x, "xT") if xT is None else xT
         ops.gemm(dyT, xT, out=out)
+
+    def _qbuf(self, tag, rows, cols):
+        """Grow-only (uint8 e4m3 [rows, cols], uint8 scales [rows, cols/32]) views for quantised transposed operands."""
+        need = rows * cols
+        buf = self._tb.get(tag)
+        if buf is None or buf[0].numel() < need:
+            buf = self._tb[tag] = (torch.empty(need, dtype=torch.uint8, device=self.dev), torch.empty(need // 32, dtype=torch.uint8, device=self.dev))
+        return buf[0][:need].view(rows, cols), buf[1][:need // 32].view(rows, cols // 32)
 
     def _lin(self, x, li, key, residual=None):
         """x @ W^T (+ residual) for decoder weight `key` of layer li: bf16 MFMA GEMM, or the MX-fp8 one."""
@@ -343,20 +363,20 @@ class FullFineTune:
             lw, sv = w.layers[li], self.saved[li]
             pre = f"layers.{li}"
             # MLP: x3 = x2 + down(silu(gate) * up)
-            self.wgrad(dx, sv["hh"], G(f"{pre}.wdown"))
+            self.wgrad(dx, sv["hh"], G(f"{pre}.wdown"), fp8=self.fp8)
             d_hh = self._lin(dx, li, "wdown_t")
             d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
-            self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"))
+            self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"), fp8=self.fp8)
             d_h2 = self._lin(d_gu, li, "wgu_t")
             ops.rmsnorm_bwd_dw(sv["x2"], d_h2, g.rms_eps, G(f"{pre}.post_norm"))
             dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
             # attention: x2 = x + o(attn(rope(qkv(norm(x)))))
-            self.wgrad(dx2, sv["a"], G(f"{pre}.wo"))
+            self.wgrad(dx2, sv["a"], G(f"{pre}.wo"), fp8=self.fp8)
             d_a = self._lin(dx2, li, "wo_t")
             dqkv = ops.attention_bwd(sv["qkv"], qd, kd, sv["a"], d_a, sv["lse"], self.key_mask, B, S, g.heads, g.kv_heads,
                                      g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta)
             ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
-            self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"))
+            self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"), fp8=self.fp8)
             d_h1 = self._lin(dqkv, li, "wqkv_t")
             ops.rmsnorm_bwd_dw(sv["x"], d_h1, g.rms_eps, G(f"{pre}.in_norm"))
             dx = ops.rmsnorm_bwd(sv["x"], lw["in_norm"], d_h1, g.rms_eps, dx_in=dx2)
