@@ -345,6 +345,10 @@ int vlb_col2im3d_k2s2p1(const void* dcols, void* dx, int B, int T, int H, int W,
 /* x bf16 [rows, K] -> q uint8 [rows, K] (e4m3, round-to-nearest-even, saturating) + scales uint8 [rows, K/32];
  * the shared exponent of a block is ceil(log2(amax / 448)).  K % 32 == 0; ld* in elements of the respective array. */
 int vlb_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int rows, int K, void* stream);
+/* The same quantisation of x^T in one pass: q uint8 [C, Rpad], scales uint8 [C, Rpad/32] with the MX blocks running along
+ * x's ROW axis (rows R..Rpad-1 quantise as zeros) - the operands of the dgrad (W^T) and wgrad (dy^T, x^T) products. */
+int vlb_transpose_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int R, int C, int Rpad,
+                                 void* stream);
 /* C[M,N] bf16 = dequant(Aq,sA)[M,K] . dequant(Wq,sW)[N,K]^T + residual (optional); fp32 accumulate.
  * N % 256 == 0, K % 128 == 0, any M. */
 int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa, const void* Wq, int ldw, const void* sW, int ldsw, void* C,

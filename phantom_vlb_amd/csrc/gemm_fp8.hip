@@ -223,6 +223,54 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16* __restr
   qp[0] = u32x4{w[0], w[1], w[2], w[3]};
   qp[1] = u32x4{w[4], w[5], w[6], w[7]};
 }
+// ---------------------------------------------------------------- transpose + quantise in one pass
+// q[C, Rpad] (e4m3) and s[C, Rpad/32] (E8M0) of x[R, C]^T: what the dgrad (W^T) and wgrad (dy^T, x^T) GEMMs of the fp8
+// path consume - MX blocks run along the ORIGINAL row axis.  Tile 128 (R) x 64 (C) through LDS: 16-byte global loads
+// along C, then one thread per (output row c, 32-element block of R): 32 LDS reads down a column, amax, shared
+// exponent, v_cvt_pk_fp8_f32, one 32-byte store.  Rows R..Rpad-1 quantise as zeros (scale byte 0).
+__global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+                                                                      uint8_t* __restrict__ s, int lds_, int R, int C, int Rpad) {
+  __shared__ bf16 tile[128][66];
+  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (t >> 3) + 32 * p, cc = (t & 7) * 8;
+    bf16x8 v{};
+    if (r0 + r < R) {
+      if (c0 + cc + 8 <= C) v = *reinterpret_cast<const bf16x8*>(x + (int64_t)(r0 + r) * ldx + c0 + cc);
+      else for (int j = 0; j < 8; ++j) if (c0 + cc + j < C) v[j] = x[(int64_t)(r0 + r) * ldx + c0 + cc + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) *reinterpret_cast<bf16x2*>(&tile[r][cc + j]) = bf16x2{v[j], v[j + 1]};
+  }
+  __syncthreads();
+  const int c = t & 63, blk = t >> 6;                      // output row c0 + c, block of 32 source rows r0 + 32*blk ..
+  if (c0 + c >= C || r0 + 32 * blk >= Rpad) return;
+  float v[32];
+  float amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { v[k] = (float)tile[32 * blk + k][c]; amax = fmaxf(amax, fabsf(v[k])); }
+  int E = -127;
+  if (amax > 0.f) {
+    int e; const float f = frexpf(amax / 448.f, &e);
+    E = (f == 0.5f) ? e - 1 : e;
+    E = max(-127, min(127, E));
+  }
+  s[(int64_t)(c0 + c) * lds_ + (r0 >> 5) + blk] = (uint8_t)(E + 127);
+  const float inv = exp2f((float)-E);
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 4] * inv, v[i * 4 + 1] * inv, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 4 + 2] * inv, v[i * 4 + 3] * inv, pk, true);
+    w[i] = (uint32_t)pk;
+  }
+  u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)(c0 + c) * ldq + r0 + 32 * blk);
+  qp[0] = u32x4{w[0], w[1], w[2], w[3]};
+  qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+}
 }  // namespace
 
 #ifdef VLB_TOOLS
@@ -257,6 +305,18 @@ extern "C" int vlb_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq,
   const int64_t total = (int64_t)rows * kb;
   hipLaunchKernelGGL(quantize_mxfp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx,
                      (uint8_t*)q, ldq, (uint8_t*)scales, lds, rows, kb);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_transpose_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int R, int C, int Rpad,
+                                            void* stream) {
+  VLB_REQUIRE(x_bf16 && q && scales && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0 && ldx % 8 == 0 && ldx >= C && ldq % 16 == 0 &&
+                  ldq >= Rpad && lds >= Rpad / 32, "transpose_quantize_mxfp8: Rpad must be a multiple of 32, ldx of 8, ldq of 16");
+  VLB_REQUIRE((((uintptr_t)x_bf16 | (uintptr_t)q) % 16) == 0, "transpose_quantize_mxfp8: 16-byte alignment required");
+  dim3 grid((C + 63) / 64, (Rpad + 127) / 128);
+  hipLaunchKernelGGL(transpose_quantize_mxfp8_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx, (uint8_t*)q, ldq,
+                     (uint8_t*)scales, lds, R, C, Rpad);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

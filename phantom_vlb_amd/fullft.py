@@ -159,15 +159,19 @@ class FullFineTune:
             if name not in self.conn_t:
                 self.conn_t[name] = torch.empty(C, R, dtype=BF16, device=self.dev)
             self._wt(wt, self.conn_t[name])
-        if decoder:
+        if decoder and not self.fp8:          # (the fp8 path quantises W^T straight from W below)
             for lw in self.w.layers:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     self._wt(lw[k], lw[k + "_t"])
-        if self.fp8:
+        if self.fp8:      # quantised W for the forward, quantised W^T (straight from W, one pass) for dgrad
             for li, lw in enumerate(self.w.layers):
-                for k in ("wqkv", "wo", "wgu", "wdown", "wqkv_t", "wo_t", "wgu_t", "wdown_t"):
-                    old = self.wq.get((li, k), (None, None))
-                    self.wq[(li, k)] = ops.quantize_mxfp8(lw[k], *old)
+                for k in ("wqkv", "wo", "wgu", "wdown"):
+                    self.wq[(li, k)] = ops.quantize_mxfp8(lw[k], *self.wq.get((li, k), (None, None)))
+                    N, K = lw[k].shape
+                    old = self.wq.get((li, k + "_t"))
+                    if old is None:
+                        old = (torch.empty(K, N, dtype=torch.uint8, device=self.dev), torch.empty(K, N // 32, dtype=torch.uint8, device=self.dev))
+                    self.wq[(li, k + "_t")] = ops.transpose_quantize_mxfp8(lw[k], old[0], old[1], N)
         dw_f = getattr(self, "dw_flipped", None)
         if dw_f is None:
             dw_f = self.dw_flipped = {}
@@ -197,13 +201,11 @@ class FullFineTune:
         """out[N, K] (bf16 view into the flat gradient buffer) = dy[M,N]^T . x[M,K].  fp8: both transposed operands are
         quantised along the token axis (MX blocks of 32 tokens) and the product runs on the MX-fp8 MFMA GEMM."""
         if fp8 and out.shape[1] % 256 == 0:
-            dyT, xT = self._transposed(dy, "dyT", 128), self._transposed(x, "xT", 128)
-            N, Mp = dyT.shape
-            K = xT.shape[0]
-            qa, sa = self._qbuf("dyTq", N, Mp)
-            qb, sb = self._qbuf("xTq", K, Mp)
-            ops.quantize_mxfp8(dyT, qa, sa)
-            ops.quantize_mxfp8(xT, qb, sb)
+            Mp = _up(dy.shape[0], 128)
+            qa, sa = self._qbuf("dyTq", dy.shape[1], Mp)
+            qb, sb = self._qbuf("xTq", x.shape[1], Mp)
+            ops.transpose_quantize_mxfp8(dy, qa, sa, Mp)          # transpose and quantise in one pass (3 B/element)
+            ops.transpose_quantize_mxfp8(x, qb, sb, Mp)
             ops.gemm_mxfp8(qa, sa, qb, sb, out=out)
             return
         dyT = self._transposed(dy, "dyT") if dyT is None else dyT

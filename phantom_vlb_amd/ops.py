@@ -498,6 +498,15 @@ def quantize_mxfp8(x, q=None, s=None):
     return q, s
 
 
+def transpose_quantize_mxfp8(x, q, s, rows_pad):
+    """(q [C, rows_pad] e4m3, s [C, rows_pad/32]) = MX quantisation of x[R, C]^T along x's row axis, one pass."""
+    R, C = x.shape
+    assert q.shape == (C, rows_pad) and s.shape == (C, rows_pad // 32) and x.stride(1) == 1
+    check(lib.vlb_transpose_quantize_mxfp8(_dev(x).data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), R, C,
+                                           rows_pad, _stream()), "vlb_transpose_quantize_mxfp8")
+    return q, s
+
+
 def gemm_mxfp8(aq, sa, wq, sw, residual=None, out=None):
     """out[M,N] bf16 = dequant(aq, sa) @ dequant(wq, sw)^T + residual."""
     M, K = aq.shape

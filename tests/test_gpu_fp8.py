@@ -37,6 +37,20 @@ def test_quantize_mxfp8_bit_exact(dev):
     assert bool(same.all()), int((~same).sum())
 
 
+def test_transpose_quantize_equals_quantize_of_the_transpose(dev):
+    from phantom_vlb_amd import ops
+    torch.manual_seed(3)
+    for R, C, ld in ((300, 200, 256), (5861, 1024, 1024), (64, 72, 72), (128, 64, 64)):
+        full = (torch.randn(R, ld) * torch.logspace(-3, 2, R)[:, None]).to(BF).to(dev)
+        x = full[:, :C]
+        Rp = (R + 127) // 128 * 128
+        q = torch.full((C, Rp), 0x55, dtype=torch.uint8, device=dev); s = torch.full((C, Rp // 32), 0x55, dtype=torch.uint8, device=dev)
+        ops.transpose_quantize_mxfp8(x, q, s, Rp)
+        xt = torch.zeros(C, Rp, dtype=BF, device=dev); xt[:, :R] = x.t()
+        q2, s2 = ops.quantize_mxfp8(xt)
+        assert torch.equal(s, s2) and torch.equal(q, q2), (R, C)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (5861, 1024, 4096), (77, 256, 256)])
 def test_gemm_mxfp8_equals_fp32_matmul_of_the_dequantised_operands(dev, M, N, K):
     from phantom_vlb_amd import ops

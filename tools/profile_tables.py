@@ -55,11 +55,14 @@ def stats(d, steps, prefix):
             if not bound and "gemm" in name:
                 bound = "mfma"
             o.write(f"\"{short(name)}\",{int(r['Calls']) / steps:.1f},{float(r['AverageNs']) / 1e3:.1f},{t / 1e6 / steps:.2f},{100 * t / tot:.2f},{bound},{ach},{unit},{frac}\n")
-    groups = {"gemm four-wave": 0, "gemm 8-wave": 0, "attention bwd": 0, "attention fwd": 0, "lora skinny": 0, "swiglu": 0, "norms": 0, "other": 0}
+    groups = {"gemm four-wave": 0, "gemm mx-fp8": 0, "gemm 8-wave": 0, "quantise/transpose": 0, "optimiser": 0, "attention bwd": 0, "attention fwd": 0, "lora skinny": 0, "swiglu": 0, "norms": 0, "other": 0}
     for r in rs:
         n, t = r["Name"], float(r["TotalDurationNs"])
         if "gemm_w4" in n or "gemm_splitk" in n: groups["gemm four-wave"] += t
+        elif "gemm_mxfp8" in n: groups["gemm mx-fp8"] += t
         elif "gemm_" in n: groups["gemm 8-wave"] += t
+        elif "quantize" in n or "transpose" in n: groups["quantise/transpose"] += t
+        elif "adamw" in n or "sumsq" in n: groups["optimiser"] += t
         elif "attn_bwd" in n or "attn_delta" in n or "attn_dkdv" in n: groups["attention bwd"] += t
         elif "attn_fwd" in n: groups["attention fwd"] += t
         elif "lora_" in n or "wgrad" in n or "transpose16" in n: groups["lora skinny"] += t
