@@ -43,69 +43,78 @@ __device__ __forceinline__ void glds4f(const void* g, void* l) {
 // (counted vmcnt, never 0 inside the loop).  Scales travel through LDS as well (global_load_lds_dword, one u32 = the
 // four block scales of a row per K-tile), so the loop holds no register-destination global load for the compiler to
 // drain the DMA queue on.
-constexpr int F_STAGE = 2 * 256 * FROW + 2 * 256 * 4;      // A image + W image + A scale words + W scale words = 66 KB
-constexpr int F_VM_PER_TILE = 18;                           // per wave: 8 + 8 x 1 KiB pieces, 1 + 1 scale pieces
+// NT = 8: 256 x 256 tile (wave block 128 x 128).  NT = 4: 256 x 128 tile (wave block 128 x 64) - the partial last
+// wave of tiles of a GEMM is re-cut into these halves so its work spreads over twice as many CUs.
+struct Fp8Launch { int tile0, split_n; };       // first tile id of this launch; 1 = whole tiles, 2 = column halves
 
-__global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p) {
+template <int NT>
+__global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = 256 * FROW;
-  constexpr int SA_OFF = 2 * A_BYTES, SW_OFF = SA_OFF + 256 * 4;
+  constexpr int A_BYTES = 256 * FROW, WROWS = 32 * NT, W_BYTES = WROWS * FROW;
+  constexpr int SA_OFF = A_BYTES + W_BYTES, SW_OFF = SA_OFF + 256 * 4;
+  constexpr int STAGE = SW_OFF + 256 * 4;                    // A image + W image + A scale words + W scale words
+  constexpr int VM = 8 + NT + 2;                             // LDS-DMA instructions per wave per K-tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // ---- tile order: XCD-contiguous runs (blocks b and b+8 share an XCD), bands of 4 row tiles
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int t;
+  // ---- work item -> tile: XCD-contiguous runs (blocks b and b+8 share an XCD) over this launch's grid, then bands of
+  // 4 row tiles over the whole tile grid
+  int w;
   {
-    const int q = ntiles / 8, r = ntiles % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int n = gridDim.x, q = n / 8, r = n % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int t = L.tile0 + w / L.split_n, half = w % L.split_n;
   const int band = t / (4 * p.tiles_n), within = t - band * 4 * p.tiles_n;
   const int band_rows = min(4, p.tiles_m - band * 4);
   const int tm = band * 4 + within % band_rows, tn = within / band_rows;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * 256 + half * 128;
   const int nk = p.K / FBK;
 
   // ---- LDS-DMA sources.  Data: a wave instruction writes 1 KiB = 8 rows x 128 B; lane -> (row, slot); source chunk =
-  // slot ^ swz(row).  Wave w owns rows 64w..64w+63 of both operands (8 pieces each).  Scales: lane l of wave w moves
-  // the u32 of row 64w + l.
-  const char* srcA[8]; const char* srcW[8];
+  // slot ^ swz(row).  Wave w owns A rows 64w..64w+63 (8 pieces) and W rows 8*NT*w.. (NT pieces).  Scales: lane l of
+  // wave w moves the u32 of A row 64w + l and of W row (64w + l) mod WROWS (for NT = 4 the upper waves repeat rows
+  // into an unused part of the scale area: every wave issues the same number of DMA instructions).
+  const char* srcA[8]; const char* srcW[NT];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int r = wave * 64 + j * 8 + (lane >> 3), s = lane & 7;
-    const int c = s ^ ((r >> 1) & 7);
-    srcA[j] = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * p.lda + c * 16;
-    srcW[j] = reinterpret_cast<const char*>(p.W) + (int64_t)(n0 + r) * p.ldw + c * 16;
+    srcA[j] = reinterpret_cast<const char*>(p.A) + (int64_t)min(m0 + r, p.M - 1) * p.lda + (s ^ ((r >> 1) & 7)) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = wave * 8 * NT + j * 8 + (lane >> 3), s = lane & 7;
+    srcW[j] = reinterpret_cast<const char*>(p.W) + (int64_t)(n0 + r) * p.ldw + (s ^ ((r >> 1) & 7)) * 16;
   }
   const char* srcSA = reinterpret_cast<const char*>(p.sA) + (int64_t)min(m0 + wave * 64 + lane, p.M - 1) * p.ldsa;
-  const char* srcSW = reinterpret_cast<const char*>(p.sW) + (int64_t)(n0 + wave * 64 + lane) * p.ldsw;
+  const char* srcSW = reinterpret_cast<const char*>(p.sW) + (int64_t)(n0 + (wave * 64 + lane) % WROWS) * p.ldsw;
   auto stage = [&](int st, int kt) {
-    char* base = smem + st * F_STAGE;
+    char* base = smem + st * STAGE;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      glds16f(srcA[j] + (int64_t)kt * FBK, base + (wave * 8 + j) * 1024);
-      glds16f(srcW[j] + (int64_t)kt * FBK, base + A_BYTES + (wave * 8 + j) * 1024);
-    }
+    for (int j = 0; j < 8; ++j) glds16f(srcA[j] + (int64_t)kt * FBK, base + (wave * 8 + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) glds16f(srcW[j] + (int64_t)kt * FBK, base + A_BYTES + (wave * NT + j) * 1024);
     glds4f(srcSA + kt * 4, base + SA_OFF + wave * 256);
     glds4f(srcSW + kt * 4, base + SW_OFF + wave * 256);
   };
   const int fr = lane & 15, g = lane >> 4;
-  f32x4 acc[8][8];
+  f32x4 acc[NT][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#define VLB_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
   stage(0, 0);
   if (nk > 1) stage(1, 1);
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nk > 1) VLB_VMCNT(VM); else VLB_VMCNT(0);
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + (kt & 1) * F_STAGE;
-    i32x8 wf[8], af[8];
-    int swb[8], sab[8];
+    const char* sb = smem + (kt & 1) * STAGE;
+    i32x8 wf[NT], af[8];
+    int swb[NT], sab[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = wn * 128 + j * 16 + fr;
+    for (int j = 0; j < NT; ++j) {
+      const int r = wn * 16 * NT + j * 16 + fr;
       const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, g));
       const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, 4 + g));
       wf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -128,28 +137,29 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p) {
     // (tools/probe_mfma_scale.py): the instruction takes both scale bytes from the register in the scale_b position
     // and ignores the scale_a register; passing the same packed register in both positions is right under either reading.
 #pragma unroll
-    for (int j = 0; j < 8; ++j) swb[j] = (swb[j] >> (8 * g)) & 0xff;
+    for (int j = 0; j < NT; ++j) swb[j] = (swb[j] >> (8 * g)) & 0xff;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sab[i] = ((sab[i] >> (8 * g)) & 0xff) << 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NT; ++j) {
         const int sc = swb[j] | sab[i];
         acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
       }
-    // tile kt+1 must have landed before the next iteration reads it: everything older than tile kt+2's 18 pieces
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt+1 must have landed before the next iteration reads it: everything older than tile kt+2's pieces
+    if (kt + 2 < nk) VLB_VMCNT(VM); else VLB_VMCNT(0);
     __builtin_amdgcn_s_barrier();
   }
+#undef VLB_VMCNT
   // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wm * 128 + i * 16 + fr;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = n0 + wn * 128 + j * 16 + 4 * g;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
       f32x4 v = acc[j][i];
       if (p.residual) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
@@ -162,6 +172,16 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p) {
       *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
     }
   }
+}
+
+template <int NT>
+int launch_fp8(const Fp8Args& a, Fp8Launch L, int grid, hipStream_t st) {
+  constexpr int LDS = 2 * (256 * FROW + 32 * NT * FROW + 2 * 256 * 4);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
+  hipLaunchKernelGGL((gemm_mxfp8_kernel<NT>), dim3(grid), dim3(256), LDS, st, a, L);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
 }
 
 // ---------------------------------------------------------------- bf16 -> MX fp8 (e4m3 + E8M0 block scales)
@@ -332,10 +352,16 @@ extern "C" int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa,
   if (residual) VLB_REQUIRE(ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0, "gemm_mxfp8: bad residual");
   Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
             M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + 255) / 256, N / 256};
-  constexpr int LDS = 2 * F_STAGE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
-  hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), LDS, as_stream(stream), a);
-  VLB_LAUNCH_CHECK();
-  return VLB_OK;
+  // One workgroup per CU: the GEMM runs in rounds of 256 tiles.  When the last round is at most 5/8 full its tiles
+  // are re-cut into 256 x 128 halves in a second launch (twice the workgroups, about 0.55 of a round each).
+  hipStream_t st = as_stream(stream);
+  const int tiles = a.tiles_m * a.tiles_n, cus = 256, rem = tiles % cus;
+  if (tiles > cus / 2 && rem > 0 && rem <= cus * 5 / 8) {
+    if (tiles - rem > 0) {
+      int rc = launch_fp8<8>(a, Fp8Launch{0, 1}, tiles - rem, st);
+      if (rc != VLB_OK) return rc;
+    }
+    return launch_fp8<4>(a, Fp8Launch{tiles - rem, 2}, 2 * rem, st);
+  }
+  return launch_fp8<8>(a, Fp8Launch{0, 1}, tiles, st);
 }

@@ -51,7 +51,9 @@ def test_transpose_quantize_equals_quantize_of_the_transpose(dev):
         assert torch.equal(s, s2) and torch.equal(q, q2), (R, C)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (5861, 1024, 4096), (77, 256, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (5861, 1024, 4096), (77, 256, 256),
+                                   (5861, 4096, 512),      # 368 tiles: one full round + 112 tiles re-cut into 256x128 halves
+                                   (3000, 3072, 256)])     # 144 tiles: everything runs as halves
 def test_gemm_mxfp8_equals_fp32_matmul_of_the_dequantised_operands(dev, M, N, K):
     from phantom_vlb_amd import ops
     torch.manual_seed(1)
