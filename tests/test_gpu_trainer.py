@@ -174,10 +174,25 @@ def test_device_prefetcher_hands_over_identical_batches(dev):
     assert len(DevicePrefetcher(loader, dev)) == len(loader)
 
 
-def test_full_finetune_config_fails_loudly(dev):
-    """BASELINE configs[4] (freeze_backbone=False, use_lora=False) is not built: it must raise, never train a
-    silently frozen backbone."""
+def test_full_finetune_through_trainer_fit_and_exact_resume(dev, tmp_path):
+    """BASELINE configs[4] (freeze_backbone=False, use_lora=False) through the runner: everything but the vision tower
+    trains; the checkpoint carries the backbone store (masters + both moments) and `fit(ckpt_path=)` resumes bit-exactly."""
     from phantom_vlb_amd.litmodule import VLBLitModule
-    m = VLBLitModule(_cfg(freeze_backbone=False, use_lora=False))
-    with pytest.raises(NotImplementedError):
-        m.configure_model()
+    from phantom_vlb_amd.trainer import TrainableCheckpoint, Trainer
+    kw = dict(freeze_backbone=False, use_lora=False, dropout_rate=0.1)
+    a = VLBLitModule(_cfg(**kw))
+    ta = Trainer(max_epochs=2, max_steps=6, val_check_interval=1.0, log_every_n_steps=1,
+                 callbacks=[TrainableCheckpoint(str(tmp_path), filename="best")])
+    ta.fit(a, _dm())
+    assert a.full is not None and ta.global_step == 6
+    st = torch.load(tmp_path / "last.ckpt", map_location="cpu", weights_only=False)
+    assert st["global_step"] == 4 and len(st["stores"]) == 1 and st["stores"][0]["master"].numel() == a.full.flat.numel
+    assert "model.layers.0.self_attn.q_proj.weight" in st["state_dict"] and "model.mm_projector.sampler.0.weight" in st["state_dict"]
+    assert not any(k.startswith("model.vision_tower") for k in st["state_dict"])          # the tower is frozen, not saved
+    b = VLBLitModule(_cfg(**kw))
+    tb = Trainer(max_epochs=2, max_steps=6, val_check_interval=1.0, log_every_n_steps=1)
+    tb.fit(b, _dm(), ckpt_path=str(tmp_path / "last.ckpt"))
+    assert torch.equal(a.full.flat.master, b.full.flat.master) and torch.equal(a.full.flat.compute, b.full.flat.compute)
+    assert torch.equal(a.flat.master, b.flat.master)
+    lw = b.backbone.w.layers[0]
+    assert torch.equal(lw["wo_t"], lw["wo"].t())
