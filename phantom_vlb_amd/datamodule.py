@@ -4,10 +4,11 @@ VLBDatasets; src/datamodule/videollama2_vlb_datamodule.py:24-238).
 Same sample schema (6 arrays per sample: timeseries, vision, language as fp32 tensors; padvals,
 vis_weights, lang_weights as numpy), same file-level train/val split (one random file is the
 validation set, ``np.random.RandomState(random_state).choice``), same ``$SCRATCH_PATH`` /
-``s*`` -> season substitution, same DataLoader settings.  Two additions because this environment
-has neither h5py nor the CNeuroMod files:
-  * ``.npz`` lazy-load files with the same keys (``{i}_{mod}`` + ``dset_len``) are read when h5py is
-    absent (tools/h5_to_npz.py converts on a machine that has h5py);
+``s*`` -> season substitution, same DataLoader settings.  HDF5 sample stores are read with h5py
+when it is installed and with the package's own pure-Python reader (``h5lite``, pinned against files written by the real
+h5py) otherwise.  Two additions because this environment has no CNeuroMod files:
+  * ``.npz`` lazy-load files with the same keys (``{i}_{mod}`` + ``dset_len``) are read too
+    (tools/h5_to_npz.py converts);
   * ``lazyload_path: synthetic:<n_files>x<samples>`` yields seeded synthetic samples.
 """
 from __future__ import annotations
@@ -55,10 +56,22 @@ class VLBDataModuleConfig:
     num_target: int = 1000
 
 
-class _H5File:
-    def __init__(self, path):
+def open_h5(path):
+    """h5py when it is installed, else the package's own read-only HDF5 subset (h5lite) - same indexing surface."""
+    try:
         import h5py
-        self.f = h5py.File(path, "r")
+        return h5py.File(path, "r")
+    except ImportError:
+        from . import h5lite
+        return h5lite.File(path)
+
+
+class _H5File:
+    """The reference's lazy-load sample store (src/preprocessing/videollama2_vlb_lazyloading.py:141-164), read exactly
+    as its VLB_Dataset does (src/datamodule/...:83-109): f["{i}"]["{i}_{mod}"], f["dset_len"][0]."""
+
+    def __init__(self, path):
+        self.f = open_h5(path)
         self.length = int(np.array(self.f["dset_len"])[0])
 
     def get(self, i, mod):

@@ -146,15 +146,12 @@ def align_run(episode: Mapping[str, np.ndarray], run_bold: np.ndarray, window: i
 # Containers
 # --------------------------------------------------------------------------------------------------
 class _Hdf5Groups:
-    """Read-only `{group: {dataset: array}}` view of an HDF5 file (gzip is transparent to h5py)."""
+    """Read-only `{group: {dataset: array}}` view of an HDF5 file: h5py when installed, else the package's own reader
+    (h5lite: chunked gzip-4 datasets, the format ..._extractfeatures.py:443-508 writes, are supported)."""
 
     def __init__(self, path):
-        try:
-            import h5py
-        except ImportError as e:                                   # pragma: no cover - depends on the image
-            raise ImportError(f"{path}: reading HDF5 needs h5py; convert to .npz where h5py exists "
-                              "(tools/h5_to_npz.py --episodes)") from e
-        self.f = h5py.File(path, "r")
+        from .datamodule import open_h5
+        self.f = open_h5(path)
 
     def keys(self):
         return list(self.f.keys())
