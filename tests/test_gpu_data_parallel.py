@@ -22,7 +22,7 @@ def _cfg(lora):
                               lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini")
 
 
-def _worker(rank, world, port, lora, ret):
+def _worker(rank, world, port, lora, ret, shard_frozen=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -45,6 +45,11 @@ def _worker(rank, world, port, lora, ret):
             opt, _ = m.configure_optimizers()
             return m, opt[0]
         m, opt = build()
+        if shard_frozen:                  # fsdp.yaml-equivalent layout of the frozen decoder: 1/2 of every layer per rank
+            full_bytes = sum(lw[k].numel() * 2 for lw in m.backbone.w.layers for k in ("wqkv", "wo", "wgu", "wdown"))
+            m.backbone.enable_sharding()
+            assert m.backbone.w.layers[0]["wqkv"] is None and m.backbone.store.world == 2
+            assert m.backbone.store.shard_bytes() <= full_bytes // 2 + 64 * len(m.backbone.w.layers)
         st = attach_data_parallel(m, opt)
         assert m.world_size == 2 and st.active and st.numel * 2 == m.flat.numel and m.flat.m is None
         mine = {k: v[rank * 2:rank * 2 + 2] for k, v in full.items()}
@@ -77,6 +82,17 @@ def test_two_rank_gradients_match_single_process(dev, lora):
     assert ret[0]["perr"] < 2.5e-3, ret[0]["perr"]                         # one AdamW step of lr 1e-3: |update| <= lr
     assert torch.equal(ret[0]["master"], ret[1]["master"])                 # ranks stay in lock-step
     assert torch.equal(ret[0]["compute"], ret[1]["compute"])
+
+
+def test_two_rank_lora_with_sharded_frozen_weights(dev):
+    """`--shard-frozen` at world 2: every decoder layer (and its transposed copy) lives as two half shards, all-gathered
+    one layer ahead in forward and in reverse for backward; gradients and the updated parameters equal the replicated run."""
+    import random
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, 29600 + random.randint(0, 2000), True, ret, True), nprocs=2, join=True)
+    assert ret[0]["err"] < 4e-2 and ret[0]["perr"] < 2.5e-3
+    assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
 
 
 def _worker_full(rank, world, port, ret):
