@@ -75,7 +75,7 @@ class FlatTrainables:
                 blk = lora.layers[li][gname]
                 o0 = offs[a_names[0]][0]
                 R, kin = blk["A"].shape
-                assert all(offs[a_names[j]][0] == o0 + j * 16 * kin for j in range(len(a_names)))
+                assert all(offs[a_names[j]][0] == o0 + j * lora.rp * kin for j in range(len(a_names)))
                 for n in a_names + b_names:
                     view(self.master, n).copy_(lora.master[n])
                     lora.master[n] = view(self.master, n)

@@ -8,8 +8,9 @@ A kaiming-uniform(a=sqrt 5), B zero.  (peft matches target names by suffix, so u
 ``q_proj/k_proj/v_proj`` could be wrapped too; the tower is frozen and BASELINE.json says "LoRA on
 attn/MLP", so only the 7 decoder linears are adapted - SURVEY.md 7.2.)
 
-MI355X layout: projections that share an input share one skinny launch (q,k,v -> R=48; gate,up ->
-R=32); the adapter's up-projection rides in the base GEMM as a second operand pair (t | B), so
+MI355X layout: projections that share an input share one skinny launch (at r = 16: q,k,v -> R=48; gate,up ->
+R=32; larger ranks are stacks of 16-rank blocks, 48 ranks per launch); the adapter's up-projection rides in the base
+GEMM as a second operand pair (t | B), so
 adapted and base outputs are accumulated in the same MFMA accumulators; dgrad uses the transposed
 frozen weights laid down once at load time.  Masters are fp32 ``A [r,in]`` and ``B^T [r,out]``.
 """
@@ -77,19 +78,22 @@ GROUPS = (
 class LoraState:
     def __init__(self, g: Geometry, weights, r: int, alpha: int, dropout: float, device, seed: int = 1234,
                  sd: dict | None = None, target_modules=None):
-        """``r``: any rank 1..16 (the reference's field is a free int, litmodule :141; its YAML sets 16).  The
-        adapter kernels work on one 16-wide MFMA tile per projection, so smaller ranks are zero-padded to 16 rows:
+        """``r``: any rank 1..64 (the reference's field is a free int, litmodule :141; its YAML sets 16, upstream
+        VideoLLaMA2 recipes 64).  The adapter kernels work on 16-wide MFMA tiles, so a projection's adapter is
+        ``c = ceil(r/16)`` stacked 16-rank blocks (same dropout mask: same seed) and the last block is zero-padded:
         padded rows of A and B^T are zero, receive exactly zero gradients (t = x.0, u = dy.0) and stay zero under
         AdamW; ``state_dict`` / ``load_state_dict`` expose the true [r, in] / [out, r] shapes.
         ``target_modules``: leaf names from ``find_all_linear_names`` - must be the seven decoder linears."""
-        if not isinstance(r, int) or not 1 <= r <= 16:
-            raise NotImplementedError(f"lora_r={r}: ranks 1..16 are built (one 16-wide MFMA tile per adapted projection); "
+        if not isinstance(r, int) or not 1 <= r <= 64:
+            raise NotImplementedError(f"lora_r={r}: ranks 1..64 are built (up to four 16-wide MFMA tiles per adapted projection); "
                                       "the reference's setting is 16 (config/experiment/VLB_vllama2_friends_lora.yaml:27)")
         want = sorted(t.split(".")[-1] for _, ts in GROUPS for t in ts)
         if target_modules is not None and sorted(target_modules) != want:
             raise NotImplementedError(f"LoRA target_modules {sorted(target_modules)}: the adapted decoder is built for "
                                       f"exactly {want}")
         self.g, self.w, self.r, self.dev = g, weights, r, device
+        self.c = c = (r + 15) // 16          # 16-rank blocks per projection
+        self.rp = rp = 16 * c                # padded rank (rows of A / B^T per projection)
         self.scale = alpha / r
         self.p = float(dropout)
         self.step = 0
@@ -108,15 +112,16 @@ class LoraState:
         for i in range(g.layers):
             lay = {}
             for gname, targets in GROUPS:
-                R = 16 * len(targets)
+                R = rp * len(targets)
+                Rpad = (R + PAD - 1) // PAD * PAD                                  # K2 of the fused GEMM: whole 64-wide K-tiles
                 kin = self.in_dims[targets[0]]
                 A = torch.zeros(R, kin, dtype=BF16, device=device)                 # stacked adapters (compute copy)
                 nout = sum(self.out_dims[t] for t in targets)
-                lay[gname] = dict(A=A, At=torch.zeros(kin, PAD, dtype=BF16, device=device),
-                                  Bpad=torch.zeros(nout, PAD, dtype=BF16, device=device), R=R, targets=targets)
+                lay[gname] = dict(A=A, At=torch.zeros(kin, Rpad, dtype=BF16, device=device),
+                                  Bpad=torch.zeros(nout, Rpad, dtype=BF16, device=device), R=R, Rpad=Rpad, targets=targets)
                 for j, t in enumerate(targets):
                     pre = f"model.layers.{i}.{t}"
-                    a0, b0 = torch.zeros(16, kin), torch.zeros(16, self.out_dims[t])
+                    a0, b0 = torch.zeros(rp, kin), torch.zeros(rp, self.out_dims[t])
                     if sd is not None and f"{pre}.lora_A.weight" in sd:
                         a_in, b_in = sd[f"{pre}.lora_A.weight"].float(), sd[f"{pre}.lora_B.weight"].float()
                         if tuple(a_in.shape) != (r, kin) or tuple(b_in.shape) != (self.out_dims[t], r):
@@ -125,7 +130,7 @@ class LoraState:
                         a0[:r], b0[:r] = a_in, b_in.t()
                     else:
                         bound = 1.0 / math.sqrt(kin)           # kaiming_uniform(a=sqrt(5))
-                        a0[:r] = (torch.rand(16, kin, generator=gen)[:r] * 2 - 1) * bound
+                        a0[:r] = (torch.rand(rp, kin, generator=gen)[:r] * 2 - 1) * bound
                     self.master[f"{pre}.lora_A.weight"] = a0.to(device).contiguous()
                     self.master[f"{pre}.lora_B.weight"] = b0.to(device).contiguous()    # stored as B^T [r,out]
             self.layers.append(lay)
@@ -135,11 +140,11 @@ class LoraState:
         for i in range(g.layers):
             ga = {}
             for gname, targets in GROUPS:
-                buf = torch.zeros(16 * len(targets), self.in_dims[targets[0]], dtype=torch.float32, device=device)
+                buf = torch.zeros(rp * len(targets), self.in_dims[targets[0]], dtype=torch.float32, device=device)
                 ga[gname] = buf
                 for j, t in enumerate(targets):
-                    self.grads[f"model.layers.{i}.{t}.lora_A.weight"] = buf[16 * j:16 * j + 16]
-                    self.grads[f"model.layers.{i}.{t}.lora_B.weight"] = torch.zeros(16, self.out_dims[t], dtype=torch.float32, device=device)
+                    self.grads[f"model.layers.{i}.{t}.lora_A.weight"] = buf[rp * j:rp * j + rp]
+                    self.grads[f"model.layers.{i}.{t}.lora_B.weight"] = torch.zeros(rp, self.out_dims[t], dtype=torch.float32, device=device)
             self.grad_A.append(ga)
         # bf16 compute copies the optimiser refreshes in place: A rows inside the stacked matrix, B^T separate
         self.bt = {n: torch.zeros(t.shape, dtype=BF16, device=device) for n, t in self.master.items() if "lora_B" in n}
@@ -156,7 +161,7 @@ class LoraState:
             for gname, targets in GROUPS:
                 for j, t in enumerate(targets):
                     pre = f"model.layers.{i}.{t}"
-                    out[f"{pre}.lora_A.weight"] = lay[gname]["A"][16 * j:16 * j + 16]
+                    out[f"{pre}.lora_A.weight"] = lay[gname]["A"][self.rp * j:self.rp * j + self.rp]
                     out[f"{pre}.lora_B.weight"] = self.bt[f"{pre}.lora_B.weight"]
         return out
 
@@ -176,10 +181,13 @@ class LoraState:
                 for j, t in enumerate(targets):
                     pre = f"model.layers.{i}.{t}"
                     a, bt = cc[f"{pre}.lora_A.weight"], cc[f"{pre}.lora_B.weight"]
-                    for src, dst, n in ((a, blk["At"][:, 16 * j:], a.shape[1]), (bt, blk["Bpad"][row:, 16 * j:], bt.shape[1])):
-                        assert src.is_contiguous() and src.shape[0] == 16 and dst.stride(0) == PAD
-                        for n0 in range(0, n, 256):
-                            rec.append(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), n, n0, PAD, 0))
+                    for b in range(self.c):            # one 16-row block at a time (the kernel transposes 16 x 256 pieces)
+                        col = self.rp * j + 16 * b
+                        for src, dst, n in ((a[16 * b:16 * b + 16], blk["At"][:, col:], a.shape[1]),
+                                            (bt[16 * b:16 * b + 16], blk["Bpad"][row:, col:], bt.shape[1])):
+                            assert src.is_contiguous() and src.shape[0] == 16 and dst.stride(0) == blk["Rpad"]
+                            for n0 in range(0, n, 256):
+                                rec.append(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), n, n0, blk["Rpad"], 0))
                     row += self.out_dims[t]
         buf = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(self.dev)
         self._jobs, self._jobs_key, self._n_jobs = buf, key, len(rec)
@@ -219,9 +227,16 @@ class LoraState:
             kmax = max(g.ff, g.dim, g.heads * g.head_dim)
             self._ws = dict(cap=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
                             uws=torch.empty(lib.vlb_wgrad_u_ws_floats(M, kmax), dtype=torch.float32, device=d),
-                            u_full=torch.zeros(M, PAD, dtype=BF16, device=d))
+                            u_full=torch.zeros(M, self._rpad_max(), dtype=BF16, device=d))
         self._ws["u"] = self._ws["u_full"][:M]
         return self._ws
+
+    def _rpad_max(self):
+        return max(blk["Rpad"] for blk in self.layers[0].values())
+
+    def _group_seeds(self, seeds, n_targets):
+        """One seed per 16-rank block: the c blocks of a projection share its dropout mask."""
+        return None if seeds is None else [seeds[j] for j in range(n_targets) for _ in range(self.c)]
 
     # ------------------------------------------------------------------ forward with saved activations
     def _t_buffer(self, li, gi, M):
@@ -229,12 +244,16 @@ class LoraState:
         (the fused GEMM's K2 = 64 operand), so no per-call fill; grow-only when a packed batch is larger."""
         if getattr(self, "_t_cap", 0) < M:
             self._t_cap = M
-            self._t_bufs = torch.zeros(len(self.layers), len(GROUPS), M, PAD, dtype=BF16, device=self.dev)
-        return self._t_bufs[li, gi, :M]
+            self._t_bufs = torch.zeros(len(self.layers), len(GROUPS), M, self._rpad_max(), dtype=BF16, device=self.dev)
+        return self._t_bufs[li, gi, :M, :self.layers[li][GROUPS[gi][0]]["Rpad"]]
 
     def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None):
-        t = self._t_buffer(*slot, x.shape[0]) if slot is not None else torch.zeros(x.shape[0], PAD, dtype=BF16, device=self.dev)
-        lora_down(x, blk["A"], blk["R"], self.scale, self.p if p is None else p, seeds, t)
+        t = self._t_buffer(*slot, x.shape[0]) if slot is not None else torch.zeros(x.shape[0], blk["Rpad"], dtype=BF16, device=self.dev)
+        p = self.p if p is None else p
+        gs = self._group_seeds(seeds, len(blk["targets"])) if p > 0 else None
+        for r0 in range(0, blk["R"], 48):                       # the skinny kernel takes up to three 16-rank blocks per launch
+            n = min(48, blk["R"] - r0)
+            lora_down(x, blk["A"][r0:r0 + n], n, self.scale, p, None if gs is None else gs[r0 // 16:(r0 + n) // 16], t[:, r0:])
         return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
 
     def forward(self, backbone, vision_f32, ids, layout=None, train=True):
@@ -305,17 +324,25 @@ class LoraState:
         ws = self._workspace(dy.shape[0])
         u = ws["u"]
         col = 0
+        u = u[:, :lay["Rpad"]]
+        rp = self.rp
         for j, tname in enumerate(lay["targets"]):
             n = self.out_dims[tname]
             pre = f"model.layers.{li}.{tname}"
             dyj = dy[:, col:col + n]
-            # one pass over dy_j: dB^T[r,out] = sum_m t[m,r] dy[m,out] (t carries s and 1/(1-p))  and
+            # one pass over dy_j per 16-rank block: dB^T[r,out] = sum_m t[m,r] dy[m,out] (t carries s and 1/(1-p))  and
             # u_j = s * dy_j . B_j for the dA / dx terms below
-            wgrad_skinny_u(t[:, 16 * j:16 * j + 16], dyj, self.grads[f"{pre}.lora_B.weight"], ws["wg"],
-                           self.bt[f"{pre}.lora_B.weight"], self.scale, u[:, 16 * j:16 * j + 16], ws["uws"])
+            for b in range(self.c):
+                k = rp * j + 16 * b
+                wgrad_skinny_u(t[:, k:k + 16], dyj, self.grads[f"{pre}.lora_B.weight"][16 * b:16 * b + 16], ws["wg"],
+                               self.bt[f"{pre}.lora_B.weight"][16 * b:16 * b + 16], self.scale, u[:, k:k + 16], ws["uws"])
             col += n
-        # dA[r,in] = sum_m u[m,r] keep_g(x[m,in])/(1-p) for every projection of the group in one pass over x
-        wgrad_skinny(u, x_in, self.grad_A[li][gname], ws["wg"], lay["R"], p=self.p, seeds=seeds)
+        # dA[r,in] = sum_m u[m,r] keep_g(x[m,in])/(1-p) for every projection of the group in one pass over x (48 ranks per launch)
+        gs = self._group_seeds(seeds, len(lay["targets"])) if self.p > 0 else None
+        for r0 in range(0, lay["R"], 48):
+            n = min(48, lay["R"] - r0)
+            wgrad_skinny(u[:, r0:], x_in, self.grad_A[li][gname][r0:r0 + n], ws["wg"], n, p=self.p,
+                         seeds=None if gs is None else gs[r0 // 16:(r0 + n) // 16])
         if not need_dx:
             return None
         if self.p == 0.0:
@@ -328,7 +355,9 @@ class LoraState:
             dx = ops.gemm_masked_pair(dy, W_t, u, lay["At"], self.p, seeds[0])
         else:
             dx = ops.gemm(dy, W_t)
-            lora_dx_masked(u, lay["At"], dx, lay["R"], self.p, seeds)
+            for r0 in range(0, lay["R"], 48):
+                n = min(48, lay["R"] - r0)
+                lora_dx_masked(u[:, r0:], lay["At"][:, r0:], dx, n, self.p, gs[r0 // 16:(r0 + n) // 16])
         return dx if swiglu_gu is None else ops.swiglu_bwd(swiglu_gu, dx)
 
     def backward(self, backbone, dhidden):

@@ -352,3 +352,54 @@ def test_gemm_masked_pair_swiglu_bwd_matches_two_kernels(dev, M, ff, K):
     assert rel_err(fused, ref) < 6e-3
     again = ops.gemm_masked_pair_swiglu_bwd(dy, W, gu, u, At, p, seed)
     assert torch.equal(fused, again)
+
+
+@pytest.mark.parametrize("r,p", [(40, 0.0), (32, 0.1), (64, 0.1), (8, 0.1)])
+def test_mini_lora_other_ranks_match_oracle(dev, r, p):
+    """The reference's lora_r is a free int (litmodule :141): ranks that need several 16-wide MFMA blocks per projection
+    (32, 40 - last block padded -, 64) and a rank below one block (8), without and with dropout (the c blocks of a
+    projection share one mask), every adapter gradient against oracle autograd fed the same masks."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule
+    from phantom_vlb_amd.lora import GROUPS
+    g = O.geometry_mini(lora_r=r, lora_alpha=32)
+    pp = O.round_bf16(O.init_params(g, seed=5, lora=True, lora_b_std=0.05))
+    batch = O.synthetic_batch(g, 2, seed=6)
+    cfg = dataclasses.replace(_lora_cfg(p), lora_r=r)
+    m = VLBLitModule(cfg)
+    m.configure_model(state_dict=pp)
+    assert m.lora.c == (r + 15) // 16 and m.lora.layers[0]["qkv"]["R"] == 3 * 16 * m.lora.c
+    opt, _ = m.configure_optimizers()
+    loss = m.training_step(batch)
+    lens = m.backbone.row_layout(batch["language"], batch["padvals"]).lens
+    M = sum(lens)
+
+    def dense(mask):
+        out = torch.ones(2, g.max_len, mask.shape[1])
+        out[0, :lens[0]], out[1, :lens[1]] = mask[:lens[0]], mask[lens[0]:]
+        return out
+    drop = None
+    if p > 0:
+        drop = {}
+        for li in range(g.layers):
+            idx = 0
+            for gname, targets in GROUPS:
+                for t in targets:
+                    drop[f"model.layers.{li}.{t}"] = dense(keep_mask(m.lora._seed(li, idx), M, m.lora.in_dims[t], p).float() / (1 - p))
+                    idx += 1
+    names = O.trainable_names(pp, False, True)
+    pr = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in pp.items()}
+    loss_ref, _ = O.training_loss(pr, batch, g, lora_drop=drop)
+    loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 1e-3
+    sd_grads = {n: (t[:r].t() if "lora_B" in n else t[:r]) for n, t in m.lora.grads.items()}
+    worst = max(rel_err(sd_grads[n], pr[n].grad) for n in sd_grads)
+    assert worst < 6e-2, worst
+    for n, t in m.lora.grads.items():                         # padded rank rows receive exactly zero gradient
+        if t.shape[0] > r:
+            assert float(t[r:].abs().max()) == 0.0, n
+    opt[0].step()
+    sd = m.trainable_state_dict()
+    assert sd["model.layers.0.self_attn.k_proj.lora_A.weight"].shape == (r, g.dim)
+    assert sd["model.layers.0.self_attn.k_proj.lora_B.weight"].shape == (g.kv_heads * g.head_dim, r)
