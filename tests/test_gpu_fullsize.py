@@ -406,3 +406,50 @@ def test_7b_lora_step_init_properties(dev):
     assert abs(frozen - loss) <= 3e-3 * abs(loss), (frozen, loss)
     del m
     torch.cuda.empty_cache()
+
+
+def test_full_finetune_backward_full_size_vs_oracle(dev):
+    """configs[4]'s backward at BASELINE widths: ONE 12-frame clip through 2 ViT-L layers (frozen), the FULL STC connector
+    (2 x 4 RegStage blocks at 4096 channels, Conv3d 12x24x24 -> 7x13x13, readout MLP), the token splice and ONE
+    Mistral-7B-sized decoder layer + final norm - every weight gradient of connector, embed_tokens (32000 x 4096) and
+    decoder (wgrad GEMMs on transposed activations at M=2048, norm gains) against oracle autograd."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.backbone import Backbone, Weights
+    from phantom_vlb_amd.fullft import FullFineTune
+    from phantom_vlb_amd.geometry import geometry_7b
+    go = dataclasses.replace(O.geometry_7b(), layers=1, vit_layers=3)
+    p = O.round_bf16(O.init_params(go, seed=21))
+    g = dataclasses.replace(geometry_7b(), layers=1, vit_layers=3)
+    batch = O.synthetic_batch(go, 1, seed=22)
+    S = g.max_len
+    gen = torch.Generator().manual_seed(23)
+    gout = (torch.randn(1, S, g.dim, generator=gen) * 0.05).to(BF)
+    trained = [n for n in p if n.startswith("model.") and not n.startswith("model.vision_tower.")]      # the head is not on this path
+    pr = {k: (v.clone().requires_grad_(True) if k in trained else v) for k, v in p.items()}
+    hid_ref, km = O.backbone_forward(pr, batch, go)
+    gout = gout * km[..., None].to(BF)                     # the head never weights padded rows
+    (hid_ref * gout.float()).sum().backward()
+    bb = Backbone(g, Weights(g, p, dev, keep_transposed=True))
+    full = FullFineTune(g, bb, dev)
+    ids = batch["language"].long()
+    hidden, _ = full.forward(batch["vision"].to(dev), ids.to(dev), layout=None, ids_host=ids)
+    assert rel_err(hidden.view(1, S, g.dim).float().cpu() * km[..., None], hid_ref.detach() * km[..., None]) < 3e-2
+    full.backward(gout.to(dev).view(S, g.dim).contiguous())
+    torch.cuda.synchronize()
+    grads = full.state_dict("grad")
+    assert set(grads) == set(trained)
+    worst = {}
+    for n, gk in grads.items():
+        ref = pr[n].grad
+        assert ref is not None and gk.shape == ref.shape, n
+        worst[n] = float((gk - ref).abs().max() / (ref.abs().max() + 1e-20))
+    bad = {n: e for n, e in worst.items() if e > 8e-2}
+    assert not bad, sorted(bad.items(), key=lambda t: -t[1])[:8]
+    # the embedding gradient is exactly zero for tokens that do not occur in the clip
+    used = set(ids[0].tolist()) - {-201}
+    ge = grads["model.embed_tokens.weight"]
+    unused = torch.tensor(sorted(set(range(g.vocab)) - used)[:2000])
+    assert float(ge[unused].abs().max()) == 0.0
+    del full, bb
+    torch.cuda.empty_cache()
