@@ -13,6 +13,8 @@
 // row; both operands' scales are bytes of ONE register (see the K loop).  MFMA roles are swapped like in the
 // bf16 kernel (MFMA rows = output columns) so a lane owns 4 consecutive n of one output row: 8-byte stores.
 // Scales: one byte per (row, 32-element K block); the u32 of a row's four blocks per K-tile rides the same LDS-DMA ring.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -108,8 +110,14 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
   if (nk > 1) stage(1, 1);
   if (nk > 1) VLB_VMCNT(VM); else VLB_VMCNT(0);
   __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K-tile.  MORE: tile kt+2 exists and is issued into the stage this tile was read from.  After the barrier the
+  // LDS-DMA pieces of tile kt+2 are issued two or three at a time in front of each row of NT MFMAs (sched_barrier fences
+  // pin that order), so their issue cost (60-100 cycles apiece) hides in the shadow of the previous row's MFMAs instead
+  // of standing as one burst in front of the whole MFMA phase.
+  auto tile = [&](int kt, auto more) {
+    constexpr bool MORE = decltype(more)::value;
     const char* sb = smem + (kt & 1) * STAGE;
+    char* nb = smem + (kt & 1) * STAGE;                    // stage refilled with tile kt+2
     i32x8 wf[NT], af[8];
     int swb[NT], sab[8];
 #pragma unroll
@@ -131,7 +139,6 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                          // every wave holds tile kt in registers: its stage is free
-    if (kt + 2 < nk) stage(kt & 1, kt + 2);
     // Both E8M0 scales travel in ONE register: byte 0 = the MFMA-A operand's (the W rows), byte 1 = the MFMA-B
     // operand's (the activation rows), selected by op_sel 0 / 1.  Measured on gfx950 with ROCm 7.2
     // (tools/probe_mfma_scale.py): the instruction takes both scale bytes from the register in the scale_b position
@@ -141,16 +148,29 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
 #pragma unroll
     for (int i = 0; i < 8; ++i) sab[i] = ((sab[i] >> (8 * g)) & 0xff) << 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (MORE) {
+        const int64_t ko = (int64_t)(kt + 2) * FBK;
+        glds16f(srcA[i] + ko, nb + (wave * 8 + i) * 1024);
+        if (i < NT) glds16f(srcW[i] + ko, nb + A_BYTES + (wave * NT + i) * 1024);
+        if (i == 0) glds4f(srcSA + (kt + 2) * 4, nb + SA_OFF + wave * 256);
+        if (i == 1) glds4f(srcSW + (kt + 2) * 4, nb + SW_OFF + wave * 256);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int sc = swb[j] | sab[i];
         acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // tile kt+1 must have landed before the next iteration reads it: everything older than tile kt+2's pieces
-    if (kt + 2 < nk) VLB_VMCNT(VM); else VLB_VMCNT(0);
+    if constexpr (MORE) VLB_VMCNT(VM); else VLB_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-  }
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{});
+  for (; kt < nk; ++kt) tile(kt, std::false_type{});
 #undef VLB_VMCNT
   // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}
 #pragma unroll
