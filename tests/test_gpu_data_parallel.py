@@ -172,6 +172,8 @@ def test_bench_gpus_2_launches_two_ranks(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["clips_per_gpu"]
     assert "world=2" in out["config"]["comm"]
+    sv = out["config"]["sharded_frozen_variant"]                 # the fsdp.yaml-equivalent layout is timed next to the default
+    assert sv and "error" not in sv and sv["value"] > 0, sv
     env.pop("VLB_DIST_BACKEND")
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "mini"],
