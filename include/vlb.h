@@ -312,6 +312,10 @@ int64_t vlb_norm_bwd_ws_floats(int rows, int dim);
 int64_t vlb_colsum_ws_floats(int rows, int dim);
 /* RMSNorm weight gradient: dw[c] = sum_rows dy * x * rsqrt(mean(x^2)+eps)  (modeling_mistral.py:182-196 backward) */
 int vlb_rmsnorm_bwd_dw(const void* x, const void* dy, void* dw_bf16, float* ws, int rows, int dim, float eps, void* stream);
+/* RMSNorm's whole backward in one sweep: dx = vlb_rmsnorm_bwd's result (+ dx_in when given) AND dw as above */
+int64_t vlb_rmsnorm_bwd_full_ws_floats(int rows, int dim);
+int vlb_rmsnorm_bwd_full(const void* x, const void* w, const void* dy, const void* dx_in, void* dx, void* dw_bf16, float* ws,
+                         int rows, int dim, float eps, void* stream);
 /* backward of vlb_layernorm_fwd (y = act(LN(x; w, b) + residual)): dx, d residual (may be NULL), dw, db */
 int vlb_layernorm_bwd(const void* x, const void* w, const void* b, const void* residual, const void* dy, void* dx, void* dres,
                       void* dw_bf16, void* db_bf16, float* ws, int rows, int dim, float eps, int act, void* stream);

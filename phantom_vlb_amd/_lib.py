@@ -72,6 +72,8 @@ SIGNATURES = {
     "vlb_norm_bwd_ws_floats": [I, I],
     "vlb_colsum_ws_floats": [I, I],
     "vlb_rmsnorm_bwd_dw": [P, P, P, P, I, I, F, P],
+    "vlb_rmsnorm_bwd_full_ws_floats": [I, I],
+    "vlb_rmsnorm_bwd_full": [P, P, P, P, P, P, P, I, I, F, P],
     "vlb_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, I, P],
     "vlb_act_fwd": [P, P, L, I, P],
     "vlb_act_bwd": [P, P, P, L, I, P],
@@ -101,7 +103,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
              "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64,
-             "vlb_norm_bwd_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
+             "vlb_norm_bwd_ws_floats": c_int64, "vlb_rmsnorm_bwd_full_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
 
 
 class VlbError(RuntimeError):

@@ -59,9 +59,13 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restri
 
 // ---------------------------------------------------------------- RMSNorm d gamma
 // One wave per row, RB rows per block; lane l owns columns 8l + 512k.  part[block][dim] fp32, then a fixed-order sum.
+// With w != nullptr the same pass also writes dx = rstd * (w dy) - x * mean(w dy x) rstd^3 (+ dx_in): RMSNorm's whole
+// backward in one sweep over x and dy (vlb_rmsnorm_bwd_full).
 template <int NI>
 __global__ __launch_bounds__(256) void rmsnorm_dw_partial_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
-                                                                 float* __restrict__ part, int rows, int dim, float eps, int rows_per_block) {
+                                                                 float* __restrict__ part, int rows, int dim, float eps, int rows_per_block,
+                                                                 const bf16* __restrict__ w = nullptr, const bf16* __restrict__ dx_in = nullptr,
+                                                                 bf16* __restrict__ dx = nullptr) {
   extern __shared__ float red[];                      // [4][dim]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float acc[NI][8];
@@ -91,6 +95,36 @@ __global__ __launch_bounds__(256) void rmsnorm_dw_partial_kernel(const bf16* __r
     for (int k = 0; k < NI; ++k)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[k][i] += gv[k][i] * xv[k][i] * rstd;
+    if (dx) {
+      float wv[NI][8];
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int c = lane * 8 + k * 512;
+        if (c < dim) ld8(w + c, wv[k]);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wv[k][i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dot += xv[k][i] * gv[k][i] * wv[k][i];
+      }
+      const float coef = wave_sum(dot) * rstd * rstd * rstd / dim;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int c = lane * 8 + k * 512;
+        if (c >= dim) continue;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd * wv[k][i] * gv[k][i] - coef * xv[k][i];
+        if (dx_in) {
+          float r[8]; ld8(dx_in + (int64_t)row * dim + c, r);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += r[i];
+        }
+        st8(dx + (int64_t)row * dim + c, o);
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
@@ -466,6 +500,28 @@ extern "C" int vlb_rmsnorm_bwd_dw(const void* x, const void* dy, void* dw_bf16, 
 #define VLB_RDW(NI) hipLaunchKernelGGL(rmsnorm_dw_partial_kernel<NI>, dim3(nb), dim3(256), lds, st, (const bf16*)x, (const bf16*)dy, ws, rows, dim, eps, rpb)
   if (dim <= 512) VLB_RDW(1); else if (dim <= 1024) VLB_RDW(2); else if (dim <= 2048) VLB_RDW(4); else VLB_RDW(8);
 #undef VLB_RDW
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, ws, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+// rows per block of the fused backward: enough blocks to fill the chip several times over (a memory-bound sweep)
+static inline int rms_full_rows_per_block(int rows) { int r = (rows + 1023) / 1024; return r < 4 ? 4 : (r + 3) / 4 * 4; }
+extern "C" int64_t vlb_rmsnorm_bwd_full_ws_floats(int rows, int dim) {
+  const int rpb = rms_full_rows_per_block(rows);
+  return (int64_t)((rows + rpb - 1) / rpb) * dim;
+}
+extern "C" int vlb_rmsnorm_bwd_full(const void* x, const void* w, const void* dy, const void* dx_in, void* dx, void* dw_bf16, float* ws,
+                                    int rows, int dim, float eps, void* stream) {
+  VLB_REQUIRE(x && w && dy && dx && dw_bf16 && ws && rows > 0 && dim % 8 == 0 && dim <= 4096, "rmsnorm_bwd_full: bad args (dim <= 4096)");
+  hipStream_t st = as_stream(stream);
+  const int rpb = rms_full_rows_per_block(rows), nb = (rows + rpb - 1) / rpb;
+  const int lds = 4 * dim * (int)sizeof(float);
+#define VLB_RBF(NI) hipLaunchKernelGGL(rmsnorm_dw_partial_kernel<NI>, dim3(nb), dim3(256), lds, st, (const bf16*)x, (const bf16*)dy, ws, rows, dim, eps, rpb, \
+                                       (const bf16*)w, (const bf16*)dx_in, (bf16*)dx)
+  if (dim <= 512) VLB_RBF(1); else if (dim <= 1024) VLB_RBF(2); else if (dim <= 2048) VLB_RBF(4); else VLB_RBF(8);
+#undef VLB_RBF
   VLB_LAUNCH_CHECK();
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3((dim + 31) / 32), dim3(256), 0, st, ws, nb, dim, (bf16*)dw_bf16, (float*)nullptr);
   VLB_LAUNCH_CHECK();

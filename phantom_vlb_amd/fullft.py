@@ -358,8 +358,7 @@ class FullFineTune:
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         layout = self.layout
         pos = None if layout is None else layout.pos
-        ops.rmsnorm_bwd_dw(self.x_last, dhidden, g.rms_eps, G("norm"))
-        dx = ops.rmsnorm_bwd(self.x_last, w.final_norm, dhidden, g.rms_eps)
+        dx = ops.rmsnorm_bwd_full(self.x_last, w.final_norm, dhidden, g.rms_eps, G("norm"))
         delta = torch.empty(B, g.heads, S, dtype=torch.float32, device=self.dev)
         for li in range(g.layers - 1, -1, -1):
             lw, sv = w.layers[li], self.saved[li]
@@ -370,8 +369,7 @@ class FullFineTune:
             d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
             self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"), fp8=self.fp8)
             d_h2 = self._lin(d_gu, li, "wgu_t")
-            ops.rmsnorm_bwd_dw(sv["x2"], d_h2, g.rms_eps, G(f"{pre}.post_norm"))
-            dx2 = ops.rmsnorm_bwd(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, dx_in=dx)
+            dx2 = ops.rmsnorm_bwd_full(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, G(f"{pre}.post_norm"), dx_in=dx)
             # attention: x2 = x + o(attn(rope(qkv(norm(x)))))
             self.wgrad(dx2, sv["a"], G(f"{pre}.wo"), fp8=self.fp8)
             d_a = self._lin(dx2, li, "wo_t")
@@ -380,8 +378,7 @@ class FullFineTune:
             ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
             self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"), fp8=self.fp8)
             d_h1 = self._lin(dqkv, li, "wqkv_t")
-            ops.rmsnorm_bwd_dw(sv["x"], d_h1, g.rms_eps, G(f"{pre}.in_norm"))
-            dx = ops.rmsnorm_bwd(sv["x"], lw["in_norm"], d_h1, g.rms_eps, dx_in=dx2)
+            dx = ops.rmsnorm_bwd_full(sv["x"], lw["in_norm"], d_h1, g.rms_eps, G(f"{pre}.in_norm"), dx_in=dx2)
             self.saved[li] = None
             if self.grad_hook is not None:
                 self.grad_hook(li)

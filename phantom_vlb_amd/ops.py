@@ -423,6 +423,16 @@ def rmsnorm_bwd_dw(x, dy, eps, out):
     return out
 
 
+def rmsnorm_bwd_full(x, w, dy, eps, dw_out, dx_in=None):
+    """RMSNorm backward in one sweep: returns dx (+ dx_in), writes d gamma (bf16) into dw_out."""
+    rows, dim = x.shape
+    ws = _ws(lib.vlb_rmsnorm_bwd_full_ws_floats(rows, dim), x.device, "rmsfull")
+    dx = torch.empty_like(x)
+    check(lib.vlb_rmsnorm_bwd_full(_dev(x).data_ptr(), w.data_ptr(), dy.data_ptr(), _p(dx_in), dx.data_ptr(), dw_out.data_ptr(), ws.data_ptr(),
+                                   rows, dim, eps, _stream()), "vlb_rmsnorm_bwd_full")
+    return dx
+
+
 def layernorm_bwd(x, w, b, dy, eps, dw_out, db_out, residual=None, act=ACT_NONE, want_dres=False):
     """Backward of ``layernorm(x, w, b, eps, residual, act)``: returns (dx, d residual or None); dw / db written (bf16)."""
     rows, dim = x.shape

@@ -52,6 +52,13 @@ def test_rmsnorm_bwd_dw(dev, rows, dim):
     out = torch.empty(dim, dtype=BF, device=dev)
     ops.rmsnorm_bwd_dw(x.to(dev), dy.to(dev), 1e-5, out)
     assert rel_err(out, ref) < 1e-2
+    # the fused form: same d gamma, and dx as the separate kernel's (with and without the residual gradient)
+    w, dxi = (1 + 0.1 * _r(dim, seed=5).float()).to(BF).to(dev), _r(rows, dim, seed=6).to(dev)
+    for res in (None, dxi):
+        out2 = torch.empty(dim, dtype=BF, device=dev)
+        dx = ops.rmsnorm_bwd_full(x.to(dev), w, dy.to(dev), 1e-5, out2, dx_in=res)
+        assert rel_err(out2, ref) < 1e-2          # partial sums are grouped differently from the separate kernel's
+        assert rel_err(dx, ops.rmsnorm_bwd(x.to(dev), w, dy.to(dev), 1e-5, dx_in=res)) < 4e-3
 
 
 @pytest.mark.parametrize("rows,dim,act,res", [(50, 64, 3, True), (20736, 4096, 3, True), (777, 1024, 0, False), (300, 512, 3, False),
