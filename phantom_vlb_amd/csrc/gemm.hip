@@ -36,33 +36,76 @@ struct GemmArgs {
   // workgroup per (split, tile); raw fp32 accumulators go to ws[split][tile][wave][i][j][lane][4] and
   // gemm_splitk_reduce_kernel sums the splits in a fixed order and applies the epilogue
   float* ws; int k_splits, tail_tiles;
+  int order;                // tile order (see tile_coords / xcd_remap_pid)
 };
 
-// blockIdx -> (m0, n0).  XCD-aware: blocks b and b+8 share an XCD, so each XCD gets a contiguous run of the
-// launch's tiles; tiles are walked in bands of GROUP_M row-tiles so concurrently resident tiles share A/W
-// panels in that XCD's L2.  The order is defined on the full parent grid, so a GEMM can be cut into several
-// launches (full waves with 256x256 tiles + a partial last wave re-tiled 256x128) at any tile index.
+// blockIdx -> (m0, n0).  The order is defined on the full parent grid, so a GEMM can be cut into several launches (full
+// waves with 256x256 tiles + a partial last wave re-tiled 256x128 or split along K) at any tile index.  Product order
+// (GemmArgs::order = 3): column bands of 8 tiles with the rows walked inside a band, so 32 consecutive tiles are 4 rows x
+// 8 columns (the 32 workgroups resident on one XCD share 4 A + 8 W panels in its L2), and xcd_remap_pid deals every
+// round of 256 tiles to the eight XCDs in chunks of 32: at any moment the whole chip sweeps the row panels of A against
+// the SAME 8 W panels, so a W panel comes out of HBM once and A (48-77 MB here) is re-read from the Infinity Cache.
+// Against contiguous per-XCD runs over bands of 4 row tiles (order 0: 8 XCDs in 8 different places, 96 distinct panels
+// per round instead of ~40) the same kernel measured +2 % (LoRA batch) / +7 % (frozen batch) on gate/up, -1.5 % / -2.3 %
+// on the whole step (tools/ab_step_variant.py).  Orders 0-7 exist for A/B in the tools build.
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int pid, int sub, int BM, int BN, int& m0, int& n0) {
-  constexpr int GROUP_M = 4;
-  const int band = GROUP_M * p.tiles_n;
-  const int g0 = (pid / band) * GROUP_M;
-  const int gsz = min(p.tiles_m - g0, GROUP_M);
-  const int tm = g0 + (pid % band) % gsz;
-  const int tn = (pid % band) / gsz;
+  int tm, tn;
+  if (p.order & 4) {
+    // super-bands of 16 columns walked in groups of 4 rows, each group as two 4 x 8 chunks: with the chunks of a round
+    // dealt to the XCDs (order bit 1) a chip-wide round is a 16 x 16 block of tiles = 16 A + 16 W panels
+    const int sbt = 16 * p.tiles_m;
+    const int sb = pid / sbt, c0 = sb * 16;
+    const int wd = min(p.tiles_n - c0, 16);
+    int w = pid - sb * sbt;
+    const int rg = w / (4 * wd);
+    const int gsz = min(p.tiles_m - 4 * rg, 4);
+    w -= rg * 4 * wd;
+    const int h = w / (gsz * 8);
+    const int cw = min(wd - 8 * h, 8);
+    w -= h * gsz * 8;
+    tm = 4 * rg + w / cw;
+    tn = c0 + 8 * h + w % cw;
+  } else if (p.order & 1) {
+    // column bands of 8 tiles, rows walked inside a band: 32 consecutive tiles = 4 rows x 8 columns, and one chip-wide
+    // round of 256 tiles sweeps (almost) every row panel of A against the same 8 W panels
+    constexpr int GROUP_N = 8;
+    const int band = GROUP_N * p.tiles_m;
+    const int cb = pid / band, c0 = cb * GROUP_N;
+    const int csz = min(p.tiles_n - c0, GROUP_N);
+    const int w = pid - cb * band;
+    tm = w / csz;
+    tn = c0 + w % csz;
+  } else {
+    constexpr int GROUP_M = 4;
+    const int band = GROUP_M * p.tiles_n;
+    const int g0 = (pid / band) * GROUP_M;
+    const int gsz = min(p.tiles_m - g0, GROUP_M);
+    tm = g0 + (pid % band) % gsz;
+    tn = (pid % band) / gsz;
+  }
   m0 = tm * BM;
   n0 = (tn * p.split_n + sub) * BN;
 }
 
-// blocks b and b+8 run on the same XCD: give each XCD a contiguous run of the launch's work items
-__device__ __forceinline__ int xcd_remap_pid() {
+// blocks b and b+8 run on the same XCD.  order bit 1 clear: each XCD gets one contiguous run of the launch's work items;
+// set: every round of 256 work items is dealt out in chunks of 32 (XCD x takes items [32x, 32x+32) of the round), so the
+// eight XCDs work on neighbouring tiles at the same time and share what they pull through the Infinity Cache.
+__device__ __forceinline__ int xcd_remap_pid(int order) {
   const int nblk = gridDim.x, pid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7, x = pid & 7, j = pid >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  const int x = pid & 7, j = pid >> 3;
+  int base = 0, n = nblk, jj = j;
+  if (order & 2) {
+    const int T = nblk >> 8, t = j >> 5;
+    if (t < T) return (t << 8) + (x << 5) + (j & 31);
+    base = T << 8; n = nblk - base; jj = j - (T << 5);
+  }
+  const int q = n >> 3, r = n & 7;
+  return base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + jj;
 }
 
 // returns the K split of this workgroup (0 unless the launch is a split-K tail)
 __device__ __forceinline__ int map_tile(const GemmArgs& p, int BM, int BN, int& m0, int& n0) {
-  int pid = xcd_remap_pid();
+  int pid = xcd_remap_pid(p.order);
   int sub = 0, ks = 0;
   if (p.split_n > 1) { sub = pid % p.split_n; pid /= p.split_n; }
   if (p.k_splits > 1) { ks = pid / p.tail_tiles; pid -= ks * p.tail_tiles; }   // split-major: an XCD's run shares one K range
@@ -800,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 
   if constexpr (SPLITK) {
     // work item (= remapped block id) ksplit * tail_tiles + tile owns one [4 waves][MT][NT][64 lanes][4] slab
-    float* wt = p.ws + ((int64_t)xcd_remap_pid() * 4 + wave) * (MT * NT * 256);
+    float* wt = p.ws + ((int64_t)xcd_remap_pid(p.order) * 4 + wave) * (MT * NT * 256);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -898,6 +941,7 @@ VLB_TUNABLE int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong 
                                     // when the cost model prefers them; 5 (A/B): like 3 but always 192-row tiles for long K
 VLB_TUNABLE int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 VLB_TUNABLE int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
+VLB_TUNABLE int g_tile_order = 3;   // GemmArgs::order: bit 0 column bands of 8, bit 1 XCD chunks dealt per round, bit 2 16x16 rounds (A/B: variant bits 10-12 XOR 3)
 VLB_TUNABLE int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
 
 // How the partial last wave of `tiles` tiles (nk K-tiles each) is run.  Costs are in units of one full wave of
@@ -1088,7 +1132,7 @@ extern "C" int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, 
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order;
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
@@ -1213,7 +1257,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   a.M = M; a.N = N; a.K = K; a.K2 = 64;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
   a.drop_key = lowbias32_h(seed);
@@ -1254,6 +1298,7 @@ extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_force_tile = force_tile;
   g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
   g_tail_splitk = (variant & 0x200) ? 0 : 1;   // bit 9 disables the split-K tail (A/B)
+  g_tile_order = ((variant >> 10) & 7) ^ 3;       // variant word 3 = product default (order 3)
 }
 #endif
 

@@ -58,17 +58,25 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
   constexpr int VM = 8 + NT + 2;                             // LDS-DMA instructions per wave per K-tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // ---- work item -> tile: XCD-contiguous runs (blocks b and b+8 share an XCD) over this launch's grid, then bands of
-  // 4 row tiles over the whole tile grid
+  // ---- work item -> tile (same order as gemm.hip, tile order 3): blocks b and b+8 share an XCD; every round of 256 work
+  // items is dealt to the XCDs in chunks of 32 (a partial last round in contiguous runs), and tiles are walked in column
+  // bands of 8 with the rows inside a band - a chunk is 4 rows x 8 columns, a chip-wide round sweeps the row panels of A
+  // against the same 8 W panels, which the XCDs then share through the Infinity Cache
   int w;
   {
-    const int n = gridDim.x, q = n / 8, r = n % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int T = n >> 8, tr = idx >> 5;
+    if (tr < T) {
+      w = (tr << 8) + (xcd << 5) + (idx & 31);
+    } else {
+      const int base = T << 8, nn = n - base, q = nn >> 3, r = nn & 7;
+      w = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (idx - (T << 5));
+    }
   }
   const int t = L.tile0 + w / L.split_n, half = w % L.split_n;
-  const int band = t / (4 * p.tiles_n), within = t - band * 4 * p.tiles_n;
-  const int band_rows = min(4, p.tiles_m - band * 4);
-  const int tm = band * 4 + within % band_rows, tn = within / band_rows;
+  const int band = t / (8 * p.tiles_m), c0 = band * 8, within = t - band * 8 * p.tiles_m;
+  const int band_cols = min(8, p.tiles_n - c0);
+  const int tm = within / band_cols, tn = c0 + within % band_cols;
   const int m0 = tm * 256, n0 = tn * 256 + half * 128;
   const int nk = p.K / FBK;
 
