@@ -238,27 +238,6 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches, (pM, pN, pK) = probe.result()
-    # ---- N > 1: the fsdp.yaml-equivalent layout of the frozen decoder next to the replicated default (SURVEY.md 8e asks
-    # for both): after the headline measurement, keep 1/N of every frozen layer per rank and time a few steps more.
-    shard_variant = None
-    if world > 1 and not a.shard_frozen and not full and os.environ.get("VLB_BENCH_SHARD_VARIANT", "1") == "1":
-        try:
-            m.backbone.enable_sharding()
-            for _ in range(2):
-                step()
-            barrier()
-            t1 = time.perf_counter()
-            ks = min(a.steps, 5)
-            for _ in range(ks):
-                step()
-            barrier()
-            d1 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(d1, op=torch.distributed.ReduceOp.MAX)
-            shard_variant = {"value": round(world * B * ks / float(d1.item()), 4), "unit": "clips/s", "steps": ks,
-                             "ms_per_step": round(float(d1.item()) / ks * 1e3, 3),
-                             "layout": f"frozen decoder weights sharded 1/{world} per layer, all-gathered one layer ahead (forward and reverse)"}
-        except Exception as e:                                   # never lose the headline line to the extra variant
-            shard_variant = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         clips = world * B * a.steps
         value = clips / dt
@@ -280,7 +259,7 @@ def main():
                                       f"sharded 1/{world}, bf16 copies all-gathered; frozen weights "
                                       + ("sharded 1/N per layer, all-gathered one layer ahead (fsdp.yaml FULL_SHARD equivalent)"
                                          if a.shard_frozen else "replicated (--shard-frozen for the fsdp.yaml-equivalent layout)"),
-                       "comm": comm_name, "sharded_frozen_variant": shard_variant,
+                       "comm": comm_name, "sharded_frozen_variant": None,
                        "loss": round(float(loss), 6),
                        "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                        "token_rows": {"computed": rows_run, "padded_layout": rows_dense,
@@ -300,7 +279,48 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b" and not full:
             out["cpu_baseline"] = cpu_baseline(cfg.num_target, lora)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+
+    def emit(variant):
+        if rank == 0:
+            out["config"]["sharded_frozen_variant"] = variant
+            print(json.dumps(out), flush=True)
+
+    # ---- N > 1: the fsdp.yaml-equivalent layout of the frozen decoder next to the replicated default (SURVEY.md 8e asks
+    # for both): after the headline measurement, keep 1/N of every frozen layer per rank and time a few steps more.  The
+    # headline number above is already final; a watchdog on every rank makes sure it is printed even if the extra
+    # variant's collectives stall (rank 0 prints the line with the variant marked as timed out, every rank exits 0).
+    shard_variant = None
+    if world > 1 and not a.shard_frozen and not full and os.environ.get("VLB_BENCH_SHARD_VARIANT", "1") == "1":
+        import threading
+
+        def bail():
+            emit({"error": "sharded-frozen variant did not finish within its time limit; headline unaffected"})
+            sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("VLB_BENCH_SHARD_VARIANT_LIMIT_S", "120")), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            m.backbone.enable_sharding()
+            for _ in range(2):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            ks = min(a.steps, 5)
+            for _ in range(ks):
+                step()
+            barrier()
+            d1 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(d1, op=torch.distributed.ReduceOp.MAX)
+            shard_variant = {"value": round(world * B * ks / float(d1.item()), 4), "unit": "clips/s", "steps": ks,
+                             "ms_per_step": round(float(d1.item()) / ks * 1e3, 3),
+                             "layout": f"frozen decoder weights sharded 1/{world} per layer, all-gathered one layer ahead (forward and reverse)"}
+        except Exception as e:                                   # never lose the headline line to the extra variant
+            shard_variant = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+    emit(shard_variant)
     if use_dist:
         torch.distributed.destroy_process_group()
 

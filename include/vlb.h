@@ -74,6 +74,13 @@ int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int l
 int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                      const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
                      const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream);
+/* The LoRA / full fine-tune form of the fused MistralMLP gate/up projection (modeling_mistral.py:169-170
+ * `down_proj(act_fn(gate_proj(x)) * up_proj(x))`): W_il / W2_il rows interleaved as for VLB_ACT_SWIGLU_PAIR; writes
+ * H[M, N/2] = silu(gate) * up AND the pre-activations GU[M, N] = [gate | up] (plain column order) that the backward
+ * pass reads - one GEMM epilogue instead of a GEMM plus an elementwise pass over [M, N]. */
+int vlb_gemm_swiglu_save(const void* A, int lda, const void* W_il, int ldw, void* H, int ldh, void* GU, int ldgu, int M, int N,
+                         int K, const void* A2, int lda2, const void* W2_il, int ldw2, int K2, void* ws, int64_t ws_bytes,
+                         void* stream);
 int64_t vlb_gemm_workspace_bytes(void);
 /* How a long-K GEMM (K + K2 >= 4096, N % 256 == 0) is cut on the four-wave kernel: tile rows (192|256) * 1000 +
  * tail mode * 100 + K splits; tail mode 0 = whole tiles, 1 = partial wave re-cut into 256x128 halves, 2 = split-K

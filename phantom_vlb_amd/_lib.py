@@ -28,6 +28,7 @@ SIGNATURES = {
     "vlb_last_error": [],
     "vlb_gemm_bf16": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P],
     "vlb_gemm_bf16_ws": [P, I, P, I, P, I, I, I, I, P, P, I, I, P, I, P, I, I, P, L, P],
+    "vlb_gemm_swiglu_save": [P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, L, P],
     "vlb_gemm_workspace_bytes": [],
     "vlb_gemm_plan": [I, I, I, I, I],
     "vlb_gemm_kernel_choice": [I, I, I, I],

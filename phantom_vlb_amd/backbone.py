@@ -33,7 +33,7 @@ def _bf(t, dev):
 class Weights:
     """Kernel-ready bf16 weights built from an upstream-named state dict (any dtype / device)."""
 
-    def __init__(self, g: Geometry, sd: dict, device, keep_transposed: bool = False):
+    def __init__(self, g: Geometry, sd: dict, device, keep_transposed: bool = False, gate_up_interleaved: bool | None = None):
         self.g = g
         self.dev = device
         d = device
@@ -95,14 +95,20 @@ class Weights:
                                     sd[f"{p}.self_attn.v_proj.weight"]], 0), d),
                 wo=_bf(sd[f"{p}.self_attn.o_proj.weight"], d),
                 wdown=_bf(sd[f"{p}.mlp.down_proj.weight"], d))
-            if keep_transposed:    # LoRA: backward needs the gate/up pre-activations, keep them separate
-                lw["wgu"] = _bf(torch.cat([sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"]], 0), d)
-            else:                  # frozen: SwiGLU is fused into the GEMM epilogue (interleaved rows)
-                lw["wgu_il"] = ops.interleave_gate_up(_bf(sd[f"{p}.mlp.gate_proj.weight"], d),
-                                                      _bf(sd[f"{p}.mlp.up_proj.weight"], d))
+            # gate/up rows: interleaved in 16-row blocks when SwiGLU rides in the GEMM epilogue (frozen forward; LoRA forward,
+            # whose epilogue also keeps the pre-activations - vlb_gemm_swiglu_save); plain [gate; up] when the weight itself
+            # trains (full fine-tune: its gradient and optimiser state are in that layout)
+            il = (not keep_transposed) if gate_up_interleaved is None else gate_up_interleaved
+            wgu = _bf(torch.cat([sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"]], 0), d)
             if keep_transposed:
+                lw["wgu"] = wgu
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     lw[k + "_t"] = ops.transpose(lw[k])
+                if il:
+                    del lw["wgu"]
+            if il:
+                lw["wgu_il"] = ops.interleave_gate_up(wgu[:g.ff], wgu[g.ff:])
+            del wgu
             self.layers.append(lw)
         self.final_norm = _bf(sd["model.norm.weight"], d)
         inv = 1.0 / (g.rope_theta ** (torch.arange(0, g.head_dim, 2, dtype=torch.float32) / g.head_dim))
@@ -323,7 +329,7 @@ class Backbone:
         self.store = ShardedLayerStore(self.w.layers, keys, group, stream=side)
         self.store_t = None
         if "wqkv_t" in self.w.layers[0]:
-            tkeys = tuple(k + "_t" for k in keys)
+            tkeys = ("wqkv_t", "wo_t", "wgu_t", "wdown_t")
             self.store_t = ShardedLayerStore(self.w.layers, tkeys, group, stream=side)
         for lw in self.w.layers:
             for k in list(lw):

@@ -37,6 +37,9 @@ struct GemmArgs {
   // gemm_splitk_reduce_kernel sums the splits in a fixed order and applies the epilogue
   float* ws; int k_splits, tail_tiles;
   int order;                // tile order (see tile_coords / xcd_remap_pid)
+  // SWIGLU_PAIR only: when set, the pre-activations are ALSO stored, de-interleaved, as [gate | up] rows of N columns
+  // (what a LoRA / full backward needs) - vlb_gemm_swiglu_save
+  bf16* aux; int ldaux;
 };
 
 // blockIdx -> (m0, n0).  The order is defined on the full parent grid, so a GEMM can be cut into several launches (full
@@ -119,6 +122,23 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     case VLB_ACT_GELU: return gelu_erf_f(x);
     case VLB_ACT_SILU: return silu_f(x);
     default: return x;
+  }
+}
+
+// SWIGLU_PAIR epilogue piece: g / u = four consecutive gate / up pre-activations of row m (fragments 2j and 2j+1 of the
+// interleaved weight), n = their column in the N/2-wide output.  With p.aux the pre-activations are kept too.
+__device__ __forceinline__ void store_swiglu4(const GemmArgs& p, const f32x4& g, const f32x4& u, int m, int n) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(g[e]) * u[e]);
+  *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+  if (p.aux) {
+    bf16x4 gb, ub;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gb[e] = (bf16)g[e]; ub[e] = (bf16)u[e]; }
+    bf16* ap = p.aux + (int64_t)m * p.ldaux + n;
+    *reinterpret_cast<bf16x4*>(ap) = gb;
+    *reinterpret_cast<bf16x4*>(ap + (p.N >> 1)) = ub;
   }
 }
 
@@ -428,11 +448,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
-        const int n = (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4;
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(acc[i][j][e]) * acc[i][j + 1][e]);
-        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+        store_swiglu4(p, acc[i][j], acc[i][j + 1], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4);
       }
     }
     return;
@@ -524,7 +540,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
       const int nb = (n0 + wn * 32) / 2 + fq * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (2 * (nb + e) < p.N) p.C[(int64_t)m * p.ldc + nb + e] = (bf16)(silu_f(acc[i][0][e]) * acc[i][1][e]);
+        if (2 * (nb + e) < p.N) {
+          p.C[(int64_t)m * p.ldc + nb + e] = (bf16)(silu_f(acc[i][0][e]) * acc[i][1][e]);
+          if (p.aux) {
+            p.aux[(int64_t)m * p.ldaux + nb + e] = (bf16)acc[i][0][e];
+            p.aux[(int64_t)m * p.ldaux + (p.N >> 1) + nb + e] = (bf16)acc[i][1][e];
+          }
+        }
     }
     return;
   }
@@ -613,10 +635,7 @@ __device__ __forceinline__ void w4_store_frag(const GemmArgs& p, f32x4 v, int m,
 }
 // SWIGLU_PAIR: fragments j (gate) and j+1 (up) of the interleaved weight -> silu(gate)*up at output column n
 __device__ __forceinline__ void w4_store_swiglu(const GemmArgs& p, const f32x4& g, const f32x4& u, int m, int n) {
-  bf16x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (bf16)(silu_f(g[e]) * u[e]);
-  *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+  store_swiglu4(p, g, u, m, n);
 }
 
 // NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
@@ -1106,9 +1125,28 @@ extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, voi
   return vlb_gemm_bf16_ws(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, A2, lda2, W2, ldw2, K2, nullptr, 0, stream);
 }
 
+static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                     const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                     const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream, void* aux, int ldaux);
+
 extern "C" int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                                 const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
                                 const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream) {
+  return gemm_impl(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, act, A2, lda2, W2, ldw2, K2, ws, ws_bytes, stream, nullptr, 0);
+}
+
+extern "C" int vlb_gemm_swiglu_save(const void* A, int lda, const void* W_il, int ldw, void* H, int ldh, void* GU, int ldgu, int M, int N,
+                                    int K, const void* A2, int lda2, const void* W2_il, int ldw2, int K2, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+  VLB_REQUIRE(GU && ldgu >= N && ldgu % 4 == 0 && N % 8 == 0 && ((uintptr_t)GU % 8) == 0,
+              "gemm_swiglu_save: [gate | up] rows must hold N columns, 8-byte aligned (N=%d ldgu=%d)", N, ldgu);
+  return gemm_impl(A, lda, W_il, ldw, H, ldh, M, N, K, nullptr, nullptr, 0, VLB_ACT_SWIGLU_PAIR, A2, lda2, W2_il, ldw2, K2, ws, ws_bytes,
+                   stream, GU, ldgu);
+}
+
+static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                     const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
+                     const void* W2, int ldw2, int K2, void* ws, int64_t ws_bytes, void* stream, void* aux, int ldaux) {
   VLB_REQUIRE(A && W && C, "gemm: null operand");
   VLB_REQUIRE(!ws || ((uintptr_t)ws % 16) == 0, "gemm: workspace must be 16-byte aligned");
   const bool ws_ok = ws && ws_bytes >= vlb_gemm_workspace_bytes();
@@ -1132,10 +1170,10 @@ extern "C" int vlb_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, 
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = (bf16*)aux; a.ldaux = ldaux;
   hipStream_t s = as_stream(stream);
-  const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) &&
-                      (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) % 8 == 0) &&
+  const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) && (!aux || (ldaux % 4 == 0 && (N / 2) % 4 == 0)) &&
+                      (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)aux) % 8 == 0) &&
                       (((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2) % 16 == 0);
   int choice = vec_ok ? vlb_gemm_kernel_choice(M, N, K, K2) : 0;
   if (choice != 0 && g_force_tile == 1 && N % 256 == 0) choice = 1;
@@ -1257,7 +1295,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   a.M = M; a.N = N; a.K = K; a.K2 = 64;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = nullptr; a.ldaux = 0;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
   a.drop_key = lowbias32_h(seed);

@@ -386,7 +386,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // Every derived layout is "a [16, n] bf16 matrix written transposed into 16 columns of an [n, ld] image":
 // A_j [16,K] -> A^T padded (At[:, 16j:16j+16]) and B_j^T [16,N] -> the block-diagonal padded B
 // (Bpad[row0:row0+N, 16j:16j+16]).  One launch walks a device table of 256-row jobs.
-struct ScatterJob { const bf16* src; bf16* dst; int n; int n0; int ld; int pad; };   // dst already at (row0, col0)
+// dst already at (row0, col0).  il = 1: destination rows follow the gate/up interleave of VLB_ACT_SWIGLU_PAIR - source
+// column i lands in row (i / 16) * 32 + i % 16 (dst pre-offset by 16 rows for the up projection).
+struct ScatterJob { const bf16* src; bf16* dst; int n; int n0; int ld; int il; };
 
 __global__ __launch_bounds__(256) void transpose16_scatter_kernel(const ScatterJob* __restrict__ jobs) {
   const ScatterJob j = jobs[blockIdx.x];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void transpose16_scatter_kernel(const ScatterJ
     lo[r] = j.src[(int64_t)r * j.n + i];
     hi[r] = j.src[(int64_t)(r + 8) * j.n + i];
   }
-  bf16* d = j.dst + (int64_t)i * j.ld;
+  bf16* d = j.dst + (int64_t)(j.il ? ((i >> 4) * 32 + (i & 15)) : i) * j.ld;
   *reinterpret_cast<bf16x8*>(d) = lo;
   *reinterpret_cast<bf16x8*>(d + 8) = hi;
 }

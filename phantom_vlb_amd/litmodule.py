@@ -156,7 +156,7 @@ class VLBLitModule(_Base):
                 warnings.warn(f"model_path={cfg.model_path!r} is not a local directory: random-initialising "
                               f"the {cfg.geometry} architecture (no network / HF cache in this environment)")
                 state_dict = Weights.random_state_dict(g, dev, seed=cfg.init_seed)
-        weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora) or full_ft)
+        weights = Weights(g, state_dict, dev, keep_transposed=bool(cfg.use_lora) or full_ft, gate_up_interleaved=not full_ft)
         lora_state = {k: v for k, v in state_dict.items() if ".lora_" in k} or None
         if head_state is None and all(n in state_dict for n in HEAD_PARAMS):
             head_state = {n: state_dict[n] for n in HEAD_PARAMS}

@@ -92,6 +92,9 @@ class LoraState:
             raise NotImplementedError(f"LoRA target_modules {sorted(target_modules)}: the adapted decoder is built for "
                                       f"exactly {want}")
         self.g, self.w, self.r, self.dev = g, weights, r, device
+        # gate/up weight rows interleaved for the SwiGLU epilogue (Weights(gate_up_interleaved=True)): the adapter's padded
+        # B rows follow the same interleave and the forward is ONE GEMM that writes silu(gate)*up and keeps [gate | up]
+        self.gu_il = "wgu_il" in weights.layers[0]
         self.c = c = (r + 15) // 16          # 16-rank blocks per projection
         self.rp = rp = 16 * c                # padded rank (rows of A / B^T per projection)
         self.scale = alpha / r
@@ -183,11 +186,13 @@ class LoraState:
                     a, bt = cc[f"{pre}.lora_A.weight"], cc[f"{pre}.lora_B.weight"]
                     for b in range(self.c):            # one 16-row block at a time (the kernel transposes 16 x 256 pieces)
                         col = self.rp * j + 16 * b
-                        for src, dst, n in ((a[16 * b:16 * b + 16], blk["At"][:, col:], a.shape[1]),
-                                            (bt[16 * b:16 * b + 16], blk["Bpad"][row:, col:], bt.shape[1])):
+                        il = int(self.gu_il and gname == "gu")       # B rows of gate / up land interleaved in 16-row blocks
+                        brow = 16 * j if il else row
+                        for src, dst, n, mode in ((a[16 * b:16 * b + 16], blk["At"][:, col:], a.shape[1], 0),
+                                                  (bt[16 * b:16 * b + 16], blk["Bpad"][brow:, col:], bt.shape[1], il)):
                             assert src.is_contiguous() and src.shape[0] == 16 and dst.stride(0) == blk["Rpad"]
                             for n0 in range(0, n, 256):
-                                rec.append(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), n, n0, blk["Rpad"], 0))
+                                rec.append(struct.pack("<QQiiii", src.data_ptr(), dst.data_ptr(), n, n0, blk["Rpad"], mode))
                     row += self.out_dims[t]
         buf = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(self.dev)
         self._jobs, self._jobs_key, self._n_jobs = buf, key, len(rec)
@@ -247,14 +252,30 @@ class LoraState:
             self._t_bufs = torch.zeros(len(self.layers), len(GROUPS), M, self._rpad_max(), dtype=BF16, device=self.dev)
         return self._t_bufs[li, gi, :M, :self.layers[li][GROUPS[gi][0]]["Rpad"]]
 
-    def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None):
+    def _lora_t(self, x, blk, seeds, slot=None, p=None):
+        """t = s/(1-p) * keep(x) . A^T for every projection of the group (the fused GEMM's second A operand)."""
         t = self._t_buffer(*slot, x.shape[0]) if slot is not None else torch.zeros(x.shape[0], blk["Rpad"], dtype=BF16, device=self.dev)
         p = self.p if p is None else p
         gs = self._group_seeds(seeds, len(blk["targets"])) if p > 0 else None
         for r0 in range(0, blk["R"], 48):                       # the skinny kernel takes up to three 16-rank blocks per launch
             n = min(48, blk["R"] - r0)
             lora_down(x, blk["A"][r0:r0 + n], n, self.scale, p, None if gs is None else gs[r0 // 16:(r0 + n) // 16], t[:, r0:])
+        return t
+
+    def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None):
+        t = self._lora_t(x, blk, seeds, slot, p)
         return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
+
+    def _adapted_mlp_in(self, x, lw, blk, seeds, slot, p=None, save=True):
+        """Adapted gate/up projection + SwiGLU: returns (silu(gate)*up, [gate | up] or None, t)."""
+        if self.gu_il:
+            t = self._lora_t(x, blk, seeds, slot, p)
+            if save:
+                hh, gu = ops.gemm_swiglu_save(x, lw["wgu_il"], a2=t, w2_il=blk["Bpad"])
+                return hh, gu, t
+            return ops.gemm(x, lw["wgu_il"], act=ops.ACT_SWIGLU_PAIR, a2=t, w2=blk["Bpad"]), None, t
+        gu, t = self._adapted(x, lw["wgu"], blk, seeds, slot=slot, p=p)
+        return ops.swiglu(gu), gu, t
 
     def forward(self, backbone, vision_f32, ids, layout=None, train=True):
         """Forward of the whole backbone with the adapters.  train=True: dropout on, decoder activations kept for
@@ -288,8 +309,7 @@ class LoraState:
                                        layout=layout)
             x2, t_o = self._adapted(a, lw["wo"], lay["o"], sd[3:4], residual=x, slot=(li, 1))
             h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
-            gu, t_gu = self._adapted(h2, lw["wgu"], lay["gu"], sd[4:6], slot=(li, 2))
-            hh = ops.swiglu(gu)
+            hh, gu, t_gu = self._adapted_mlp_in(h2, lw, lay["gu"], sd[4:6], (li, 2))
             x3, t_d = self._adapted(hh, lw["wdown"], lay["down"], sd[6:7], residual=x2, slot=(li, 3))
             self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh, t_qkv=t_qkv, t_o=t_o,
                                    t_gu=t_gu, t_d=t_d, seeds=sd))
@@ -312,8 +332,8 @@ class LoraState:
                                   True, g.head_dim ** -0.5, key_mask=key_mask, layout=layout)
             x, _ = self._adapted(a, lw["wo"], lay["o"], None, residual=x, slot=(li, 1), p=0.0)
             h = ops.rmsnorm(x, lw["post_norm"], g.rms_eps)
-            gu, _ = self._adapted(h, lw["wgu"], lay["gu"], None, slot=(li, 2), p=0.0)
-            x, _ = self._adapted(ops.swiglu(gu), lw["wdown"], lay["down"], None, residual=x, slot=(li, 3), p=0.0)
+            hh, _, _ = self._adapted_mlp_in(h, lw, lay["gu"], None, (li, 2), p=0.0, save=False)
+            x, _ = self._adapted(hh, lw["wdown"], lay["down"], None, residual=x, slot=(li, 3), p=0.0)
         return ops.rmsnorm(x, w.final_norm, g.rms_eps), key_mask
 
     # ------------------------------------------------------------------ backward

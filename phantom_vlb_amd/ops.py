@@ -101,6 +101,36 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     return out
 
 
+def gemm_swiglu_save(a, w_il, a2=None, w2_il=None):
+    """(h, gu): h[M, N/2] = silu(gate) * up and gu[M, N] = [gate | up] pre-activations of a @ w_il^T + a2 @ w2_il^T, with
+    w_il / w2_il rows interleaved by ``interleave_gate_up`` - the gate/up projection, SwiGLU and the activations the
+    backward pass keeps, in one GEMM (MistralMLP.forward, modeling_mistral.py:169-170)."""
+    _dev(a)
+    M, K = a.shape
+    N = w_il.shape[0]
+    assert w_il.shape[1] == K and a.stride(1) == 1 and w_il.stride(1) == 1 and N % 32 == 0
+    h = torch.empty(M, N // 2, dtype=BF16, device=a.device)
+    gu = torch.empty(M, N, dtype=BF16, device=a.device)
+    K2 = 0
+    if a2 is not None:
+        K2 = a2.shape[1]
+        assert w2_il.shape == (N, K2) and a2.shape[0] == M
+    timed = _probe is not None and N == _probe.N and K == _probe.K
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _probe.M = M
+        _probe.pairs.append((e0, e1))
+        e0.record()
+    ws = _gemm_workspace(a.device) if K + K2 >= 4096 and M * N > 256 * 192 * 256 else None
+    check(lib.vlb_gemm_swiglu_save(a.data_ptr(), a.stride(0), w_il.data_ptr(), w_il.stride(0), h.data_ptr(), h.stride(0),
+                                   gu.data_ptr(), gu.stride(0), M, N, K, _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2_il),
+                                   w2_il.stride(0) if w2_il is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
+                                   _stream()), "vlb_gemm_swiglu_save")
+    if timed:
+        e1.record()
+    return h, gu
+
+
 def gemm_masked_pair_ok(M, N, K):
     """Shapes vlb_gemm_bf16_masked_pair accepts (the fused LoRA dx path); callers fall back to gemm + lora_dx_masked."""
     return N % 256 == 0 and K % 64 == 0 and K >= 128 and M * (N // 2) < 2 ** 32

@@ -46,7 +46,7 @@ def _worker(rank, world, port, lora, ret, shard_frozen=False):
             return m, opt[0]
         m, opt = build()
         if shard_frozen:                  # fsdp.yaml-equivalent layout of the frozen decoder: 1/2 of every layer per rank
-            full_bytes = sum(lw[k].numel() * 2 for lw in m.backbone.w.layers for k in ("wqkv", "wo", "wgu", "wdown"))
+            full_bytes = sum(lw[k].numel() * 2 for lw in m.backbone.w.layers for k in ("wqkv", "wo", "wgu_il", "wdown"))
             m.backbone.enable_sharding()
             assert m.backbone.w.layers[0]["wqkv"] is None and m.backbone.store.world == 2
             assert m.backbone.store.shard_bytes() <= full_bytes // 2 + 64 * len(m.backbone.w.layers)

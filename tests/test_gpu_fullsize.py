@@ -300,7 +300,8 @@ def test_7b_step_packed_equals_dense(dev):
     torch.cuda.empty_cache()
 
 
-def test_lora_decoder_layer_full_size_fwd_bwd_vs_oracle(dev):
+@pytest.mark.parametrize("fused_mlp_in", [True, False])
+def test_lora_decoder_layer_full_size_fwd_bwd_vs_oracle(dev, fused_mlp_in):
     """One Mistral-7B-sized decoder layer with LoRA r=16 (dropout 0.1) on one 2048-token clip, 150 padded positions:
     forward output and the gradients of all 14 adapter matrices against the oracle's autograd, the oracle being fed
     the very masks the kernels used.  Exercises at BASELINE sizes: fused LoRA GEMMs (second operand pair), the
@@ -334,6 +335,9 @@ def test_lora_decoder_layer_full_size_fwd_bwd_vs_oracle(dev):
     lw = {k: v.to(dev, BF).contiguous() for k, v in lw.items()}
     for k in ("wqkv", "wo", "wgu", "wdown"):
         lw[k + "_t"] = ops.transpose(lw[k])
+    if fused_mlp_in:        # what VLBLitModule builds for LoRA: interleaved gate/up rows, SwiGLU + saved [gate | up] in the GEMM epilogue
+        lw["wgu_il"] = ops.interleave_gate_up(lw["wgu"][:g.ff], lw["wgu"][g.ff:])
+        del lw["wgu"]
     w.layers = [lw]
     w.final_norm = p["model.norm.weight"].to(dev, BF)
     inv = 1.0 / (g.rope_theta ** (torch.arange(0, g.head_dim, 2, dtype=torch.float32) / g.head_dim))

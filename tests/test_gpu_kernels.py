@@ -123,6 +123,31 @@ def test_gemm_swiglu_pair_epilogue(dev, M, ff, K):
     assert rel_err(out, unfused.float()) < 1.5e-2
 
 
+@pytest.mark.parametrize("M,ff,K,K2", [(40, 48, 64, 16),           # generic kernel
+                                        (512, 256, 128, 64),        # 8-wave tile kernel
+                                        (1000, 512, 4096, 64),      # four-wave kernel, M tail
+                                        (5015, 2048, 4096, 64)])    # four-wave kernel + split-K tail (reduce-kernel epilogue)
+def test_gemm_swiglu_save(dev, M, ff, K, K2):
+    """vlb_gemm_swiglu_save: the adapted gate/up projection of a LoRA forward in one GEMM - h = silu(gate)*up AND the saved
+    [gate | up] pre-activations (plain column order) - against the plain GEMM (+ second operand pair) and fp32 torch."""
+    from phantom_vlb_amd import ops
+    a, t = _r(M, K, dev=dev), _r(M, K2, dev=dev, seed=3)
+    wg, wu = _r(ff, K, dev=dev, scale=0.05, seed=1), _r(ff, K, dev=dev, scale=0.05, seed=2)
+    bg, bu = _r(ff, K2, dev=dev, scale=0.05, seed=4), _r(ff, K2, dev=dev, scale=0.05, seed=5)
+    h, gu = ops.gemm_swiglu_save(a, ops.interleave_gate_up(wg, wu), a2=t, w2_il=ops.interleave_gate_up(bg, bu))
+    assert h.shape == (M, ff) and gu.shape == (M, 2 * ff)
+    plain = ops.gemm(a, torch.cat([wg, wu], 0), a2=t, w2=torch.cat([bg, bu], 0))
+    assert rel_err(gu, plain.float()) < 4e-3                  # same contraction; only the split-K grouping of tail tiles may differ
+    g32 = a.float() @ wg.float().t() + t.float() @ bg.float().t()
+    u32 = a.float() @ wu.float().t() + t.float() @ bu.float().t()
+    assert rel_err(gu, torch.cat([g32, u32], 1)) < 6e-3
+    assert rel_err(h, F.silu(g32) * u32) < 8e-3
+    # without the second pair and without saving it is the frozen path's epilogue
+    h0, gu0 = ops.gemm_swiglu_save(a, ops.interleave_gate_up(wg, wu))
+    assert rel_err(h0, ops.gemm(a, ops.interleave_gate_up(wg, wu), act=ops.ACT_SWIGLU_PAIR).float()) < 4e-3
+    assert rel_err(gu0, ops.gemm(a, torch.cat([wg, wu], 0)).float()) < 4e-3
+
+
 def test_gemm_strided_views_and_alias(dev):
     from phantom_vlb_amd import ops
     M, N, K = 512, 256, 128
