@@ -40,6 +40,7 @@ struct GemmArgs {
   // SWIGLU_PAIR only: when set, the pre-activations are ALSO stored, de-interleaved, as [gate | up] rows of N columns
   // (what a LoRA / full backward needs) - vlb_gemm_swiglu_save
   bf16* aux; int ldaux;
+  int wide;                 // C (and aux) rows 16-byte aligned: required by the four-wave kernels, which store 16 bytes per lane (store_pair16)
 };
 
 // blockIdx -> (m0, n0).  The order is defined on the full parent grid, so a GEMM can be cut into several launches (full
@@ -125,6 +126,23 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   }
 }
 
+// 16-byte epilogue stores.  In the accumulator layout a lane (fr, fq) owns columns 4fq..4fq+3 of a 16-column fragment,
+// i.e. 8 bytes of bf16: the four lanes of a row would each store 8 bytes per fragment.  For two ADJACENT fragments j, j+1
+// (a = this lane's piece of j, b = of j+1) one v_permlane16_swap per dword hands the odd-fq lanes' pieces of j to their
+// even neighbours and the even lanes' pieces of j+1 to the odd ones: an even lane then holds columns 4fq..4fq+7 of
+// fragment j, an odd lane columns 4(fq-1)..4(fq-1)+7 of fragment j+1 - one 16-byte store each instead of two 8-byte
+// ones (half the store instructions of the serial tile tail, 64 contiguous bytes per row per instruction).
+// row = &C[m][0], n = the column of this lane's piece of fragment j (16-byte aligned for even fq).
+__device__ __forceinline__ void store_pair16(bf16* row, int n, bf16x4 a, bf16x4 b, int fq) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+  const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+  *reinterpret_cast<u32x4*>(row + n + ((fq & 1) ? 12 : 0)) = o;
+}
+
 // SWIGLU_PAIR epilogue piece: g / u = four consecutive gate / up pre-activations of row m (fragments 2j and 2j+1 of the
 // interleaved weight), n = their column in the N/2-wide output.  With p.aux the pre-activations are kept too.
 __device__ __forceinline__ void store_swiglu4(const GemmArgs& p, const f32x4& g, const f32x4& u, int m, int n) {
@@ -139,6 +157,23 @@ __device__ __forceinline__ void store_swiglu4(const GemmArgs& p, const f32x4& g,
     bf16* ap = p.aux + (int64_t)m * p.ldaux + n;
     *reinterpret_cast<bf16x4*>(ap) = gb;
     *reinterpret_cast<bf16x4*>(ap + (p.N >> 1)) = ub;
+  }
+}
+
+// two adjacent output fragments of the SWIGLU_PAIR epilogue (accumulator fragments 4q..4q+3) with 16-byte stores
+__device__ __forceinline__ void store_swiglu8(const GemmArgs& p, const f32x4& g0, const f32x4& u0, const f32x4& g1, const f32x4& u1,
+                                              int m, int n, int fq) {
+  bf16x4 h0, h1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { h0[e] = (bf16)(silu_f(g0[e]) * u0[e]); h1[e] = (bf16)(silu_f(g1[e]) * u1[e]); }
+  store_pair16(p.C + (int64_t)m * p.ldc, n, h0, h1, fq);
+  if (p.aux) {
+    bf16x4 ga, gb, ua, ub;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ga[e] = (bf16)g0[e]; gb[e] = (bf16)g1[e]; ua[e] = (bf16)u0[e]; ub[e] = (bf16)u1[e]; }
+    bf16* ap = p.aux + (int64_t)m * p.ldaux;
+    store_pair16(ap, n, ga, gb, fq);
+    store_pair16(ap + (p.N >> 1), n, ua, ub, fq);
   }
 }
 
@@ -594,26 +629,21 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
                : "v"(__builtin_bit_cast(i32x4_t, a)), "v"(__builtin_bit_cast(i32x4_t, b)));
 }
 
-// epilogue of one 16x16 accumulator fragment: lane holds C[m][n .. n+3]
-__device__ __forceinline__ void w4_store_frag(const GemmArgs& p, f32x4 v, int m, int n) {
-  if (p.act == VLB_ACT_SWIGLU_BWD) {
-    // v = d(silu(gate)*up) for columns n..n+3 of a [M, N = ff] product; residual = the saved [gate | up] activations
-    // (row stride ldr), C = [d gate | d up] (row stride ldc): SwiGLU backward without materialising v
-    const bf16* gp = p.residual + (int64_t)m * p.ldr + n;
-    const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(gp), u4 = *reinterpret_cast<const bf16x4*>(gp + p.N);
-    bf16x4 dg, du;
+// epilogue arithmetic of one 16x16 accumulator fragment: lane holds C[m][n .. n+3]
+// SWIGLU_BWD: v = d(silu(gate)*up) for columns n..n+3 of a [M, N = ff] product; residual = the saved [gate | up] activations
+// (row stride ldr), C = [d gate | d up] (row stride ldc): SwiGLU backward without materialising v
+__device__ __forceinline__ void w4_swiglu_bwd_value(const GemmArgs& p, const f32x4& v, int m, int n, bf16x4& dg, bf16x4& du) {
+  const bf16* gp = p.residual + (int64_t)m * p.ldr + n;
+  const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(gp), u4 = *reinterpret_cast<const bf16x4*>(gp + p.N);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = (float)g4[e], u = (float)u4[e];
-      const float sg = sigmoid_f(g);
-      du[e] = (bf16)(v[e] * (g * sg));
-      dg[e] = (bf16)(v[e] * u * (sg * (1.f + g * (1.f - sg))));
-    }
-    bf16* cp = p.C + (int64_t)m * p.ldc + n;
-    *reinterpret_cast<bf16x4*>(cp) = dg;
-    *reinterpret_cast<bf16x4*>(cp + p.N) = du;
-    return;
+  for (int e = 0; e < 4; ++e) {
+    const float g = (float)g4[e], u = (float)u4[e];
+    const float sg = sigmoid_f(g);
+    du[e] = (bf16)(v[e] * (g * sg));
+    dg[e] = (bf16)(v[e] * u * (sg * (1.f + g * (1.f - sg))));
   }
+}
+__device__ __forceinline__ bf16x4 w4_frag_value(const GemmArgs& p, f32x4 v, int m, int n) {
   if (p.bias) {
     const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
 #pragma unroll
@@ -631,13 +661,21 @@ __device__ __forceinline__ void w4_store_frag(const GemmArgs& p, f32x4 v, int m,
   bf16x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-  *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+  return o;
 }
-// SWIGLU_PAIR: fragments j (gate) and j+1 (up) of the interleaved weight -> silu(gate)*up at output column n
-__device__ __forceinline__ void w4_store_swiglu(const GemmArgs& p, const f32x4& g, const f32x4& u, int m, int n) {
-  store_swiglu4(p, g, u, m, n);
+// two adjacent fragments (columns n.. and n+16..), 16-byte stores
+__device__ __forceinline__ void w4_store_frag2(const GemmArgs& p, const f32x4& va, const f32x4& vb, int m, int n, int fq) {
+  bf16* crow = p.C + (int64_t)m * p.ldc;
+  if (p.act == VLB_ACT_SWIGLU_BWD) {
+    bf16x4 dga, dua, dgb, dub;
+    w4_swiglu_bwd_value(p, va, m, n, dga, dua);
+    w4_swiglu_bwd_value(p, vb, m, n + 16, dgb, dub);
+    store_pair16(crow, n, dga, dgb, fq);
+    store_pair16(crow + p.N, n, dua, dub, fq);
+    return;
+  }
+  store_pair16(crow, n, w4_frag_value(p, va, m, n), w4_frag_value(p, vb, m, n + 16), fq);
 }
-
 // NT = 8: 256x256 tile (wave block 128x128).  NT = 4: 256x128 tile (wave block 128x64) for the re-cut tiles
 // of a partial last wave - same pipeline, 8 MFMA groups per block instead of 16.  MT = 6: 192-row tiles (wave
 // block 96 rows), picked by the host when they quantise the row count into fewer, fuller waves of tiles.
@@ -870,13 +908,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         *reinterpret_cast<f32x4*>(wt + ((i * NT + j) * 64 + lane) * 4) = acc[i][j];
     return;
   }
+  // The four-wave kernels store 16 bytes per lane (store_pair16): the host only routes launches here whose C / aux rows are
+  // 16-byte aligned (GemmArgs::wide).  One loop nest per epilogue kind - every loop over acc[][] must unroll completely
+  // (a dynamically indexed accumulator array is moved to scratch memory, and with it the whole K loop).
   if (p.act == VLB_ACT_SWIGLU_PAIR) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * TM + i * 16 + fr;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) w4_store_swiglu(p, acc[i][j], acc[i][j + 1], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4);
+      for (int j = 0; j < NT; j += 4)
+        store_swiglu8(p, acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4, fq);
     }
     return;
   }
@@ -885,7 +927,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) w4_store_frag(p, acc[i][j], m, n0 + wn * TN + j * 16 + fq * 4);
+    for (int j = 0; j < NT; j += 2) w4_store_frag2(p, acc[i][j], acc[i][j + 1], m, n0 + wn * TN + j * 16 + fq * 4, fq);
   }
 }
 
@@ -911,11 +953,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (m >= p.M) return;
   if (p.act == VLB_ACT_SWIGLU_PAIR) {
 #pragma unroll
-    for (int j = 0; j < NT; j += 2) w4_store_swiglu(p, v[j], v[j + 1], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4);
+    for (int j = 0; j < NT; j += 4) store_swiglu8(p, v[j], v[j + 1], v[j + 2], v[j + 3], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4, fq);
     return;
   }
 #pragma unroll
-  for (int j = 0; j < NT; ++j) w4_store_frag(p, v[j], m, n0 + wn * TN + j * 16 + fq * 4);
+  for (int j = 0; j < NT; j += 2) w4_store_frag2(p, v[j], v[j + 1], m, n0 + wn * TN + j * 16 + fq * 4, fq);
 }
 
 template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
@@ -1022,7 +1064,8 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     a.grid = a.tiles_m * a.tiles_n;
   }
   // the 4-wave kernel addresses operands with 32-bit byte offsets
-  const bool fits32 = (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31) &&
+  // ... and stores 16 bytes per lane (a.wide: C / aux rows 16-byte aligned)
+  const bool fits32 = a.wide && (int64_t)a.M * a.lda < (1ll << 31) && (int64_t)a.N * a.ldw < (1ll << 31) &&
                       (int64_t)a.M * a.lda2 < (1ll << 31) && (int64_t)a.N * a.ldw2 < (1ll << 31);
 #ifndef VLB_TOOLS
   // the four-wave kernel wins once the K loop is long enough to amortise its serial prologue and epilogue (one
@@ -1171,6 +1214,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
   a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = (bf16*)aux; a.ldaux = ldaux;
+  a.wide = ((uintptr_t)C % 16) == 0 && ldc % 8 == 0 && (!aux || (((uintptr_t)aux % 16) == 0 && ldaux % 8 == 0 && (N / 2) % 8 == 0));
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) && (!aux || (ldaux % 4 == 0 && (N / 2) % 4 == 0)) &&
                       (((uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)aux) % 8 == 0) &&
@@ -1189,7 +1233,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
     // waves - e.g. M=5861, N=4096: 23x16 = 368 tiles of 256 rows cost (1 + 0.62 tail) x 256 = 415 row-units,
     // 31x16 = 496 tiles of 192 rows cost 2 x 192 = 384.  Cost = waves x tile rows; a re-cut partial wave = 0.62.
     {
-      const bool fits32 = (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) &&
+      const bool fits32 = a.wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) &&
                           (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
       const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
       const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
@@ -1267,8 +1311,8 @@ extern "C" int vlb_gemm_masked_pair_swiglu_bwd(const void* dY, int lddy, const v
                                                int lddgu, int M, int ff, int K, const void* U, int ldu, const void* At, int ldat,
                                                float drop_p, uint32_t seed, void* ws, int64_t ws_bytes, void* stream) {
   VLB_REQUIRE(gu && dgu, "gemm_masked_pair_swiglu_bwd: null activation pointers");
-  VLB_REQUIRE(ldgu >= 2 * ff && lddgu >= 2 * ff && ldgu % 4 == 0 && lddgu % 4 == 0 && ff % 4 == 0 && (((uintptr_t)gu | (uintptr_t)dgu) % 8) == 0,
-              "gemm_masked_pair_swiglu_bwd: [gate|up] rows must hold 2*ff columns, 8-byte aligned (ff=%d ldgu=%d lddgu=%d)", ff, ldgu, lddgu);
+  VLB_REQUIRE(ldgu >= 2 * ff && lddgu >= 2 * ff && ldgu % 4 == 0 && lddgu % 8 == 0 && ff % 8 == 0 && ((uintptr_t)gu % 8) == 0 && ((uintptr_t)dgu % 16) == 0,
+              "gemm_masked_pair_swiglu_bwd: [gate|up] rows must hold 2*ff columns; gu 8-byte, d gu 16-byte aligned (ff=%d ldgu=%d lddgu=%d)", ff, ldgu, lddgu);
   return masked_pair_impl(dY, lddy, Wt, ldw, dgu, lddgu, M, ff, K, U, ldu, At, ldat, drop_p, seed, ws, ws_bytes, stream,
                           VLB_ACT_SWIGLU_BWD, gu, ldgu);
 }
@@ -1282,8 +1326,8 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   VLB_REQUIRE(M > 0 && N % 256 == 0 && K >= 128 && K % 64 == 0, "gemm_masked_pair: needs N %% 256 == 0, K %% 64 == 0, K >= 128 (N=%d K=%d)", N, K);
   VLB_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0 && lda >= K && ldw >= K && lda2 >= 64 && ldw2 >= 64 &&
                   ldc % 4 == 0 && ldc >= N, "gemm_masked_pair: bad leading dimensions");
-  VLB_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2) % 16) == 0 && ((uintptr_t)C % 8) == 0,
-              "gemm_masked_pair: operands must be 16-byte aligned");
+  VLB_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2 | (uintptr_t)C) % 16) == 0 && ldc % 8 == 0,
+              "gemm_masked_pair: operands and C rows must be 16-byte aligned");
   VLB_REQUIRE(drop_p > 0.f && drop_p < 1.f, "gemm_masked_pair: drop_p must be in (0,1) - use vlb_gemm_bf16 when p == 0");
   VLB_REQUIRE((int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) && (int64_t)M * lda2 < (1ll << 31) &&
                   (int64_t)N * ldw2 < (1ll << 31) && (int64_t)M * (N >> 1) < (1ll << 32),
@@ -1296,6 +1340,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
   a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = nullptr; a.ldaux = 0;
+  a.wide = 1;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
   a.drop_key = lowbias32_h(seed);

@@ -1,0 +1,25 @@
+"""Static check of the generated gfx950 code of the four-wave GEMM kernels (no GPU needed: hipcc cross-compiles)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="hipcc not available")
+def test_four_wave_gemm_k_loops_stay_in_registers(tmp_path):
+    """Every K loop of gemm_w4_kernel holds exactly its 2 x MT x NT MFMAs, MT + NT LDS-DMA pieces and 2 (MT + NT) fragment
+    reads, and touches neither scratch memory nor v_accvgpr_* copies (tools/audit_gemm_isa.py explains why that can break
+    without any change to the loop's source)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_gemm_isa as A
+    import subprocess
+    out = str(tmp_path / "gemm.s")
+    subprocess.run([A.HIPCC if os.path.exists(A.HIPCC) else shutil.which("hipcc"), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
+                    "-Wno-unused-function", "-S", "--cuda-device-only", os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    report, bad = A.audit(out)
+    assert len(report) >= 8, report
+    assert not bad, "\n".join(bad)

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "phantom_vlb_amd", "libvlb_tools.so")
+PATH = os.environ.get("VLB_TOOLS_LIB") or os.path.join(ROOT, "phantom_vlb_amd", "libvlb_tools.so")      # VLB_TOOLS_LIB: another tools build (A/B across builds)
 if not os.path.exists(PATH):
     subprocess.run(["make", "-C", os.path.join(ROOT, "phantom_vlb_amd", "csrc"), "-j8", "tools"], check=True)
 os.environ["VLB_LIB"] = PATH
