@@ -275,8 +275,16 @@ int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* d
 int64_t vlb_wgrad_u_ws_floats(int M, int K);
 int vlb_wgrad_skinny_u(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int K, float alpha,
                        float beta, const void* Bt, float u_scale, void* u, int ldu, float* u_ws, void* stream);
+/* The same pass for the 1..3 projections that share one dY = X [M, sum cols] (q|k|v, gate|up; reference
+ * find_all_linear_names targets, litmodule :36-55): projection j owns cols[j] columns (multiples of 256), its G is
+ * t[:, 16j:16j+16), its gradient dW[j] [16, cols[j]] fp32, its Bt[j] [16, cols[j]] bf16, and u[:, 16j:16j+16) receives
+ * u_scale * dY_j . Bt[j]^T.  cols / dW / Bt are HOST arrays (of ints / device pointers).  One sweep and one reduce
+ * launch instead of one pair per projection; ws: splits * 16 * sum(cols) floats, u_ws: vlb_wgrad_u_ws_floats(M, sum cols). */
+int vlb_wgrad_skinny_u_multi(const void* G, int ldg, const void* X, int ldx, int M, int nproj, const int* cols, float* const* dW,
+                             const void* const* Bt, float* ws, float alpha, float beta, float u_scale, void* u, int ldu,
+                             float* u_ws, void* stream);
 /* Rebuild derived adapter layouts after an optimiser step in ONE launch.  jobs: device array of n_jobs
- * records {const bf16* src; bf16* dst; int32 n; int32 n0; int32 ld; int32 pad} (32 bytes): rows
+ * records {const bf16* src; bf16* dst; int32 n; int32 n0; int32 ld; int32 il} (32 bytes; il = 1: destination row (i/16)*32 + i%16 instead of i, the gate/up interleave of VLB_ACT_SWIGLU_PAIR): rows
  * [n0, n0+256) of the transpose of the row-major [16, n] matrix `src` are written to dst[i*ld + 0..15]
  * (dst points at the first row/column of the 16-column band, 16-byte aligned, ld % 8 == 0).
  * Used for At[:, 16j:16j+16] = A_j^T and Bpad[row0:row0+N, 16j:16j+16] = B_j (peft: lora_A / lora_B). */

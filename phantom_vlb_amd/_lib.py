@@ -60,6 +60,7 @@ SIGNATURES = {
     "vlb_gemm_bf16_masked_pair_ws": [P, I, P, I, P, I, I, I, I, P, I, P, I, F, ctypes.c_uint32, P, L, P],
     "vlb_wgrad_u_ws_floats": [I, I],
     "vlb_wgrad_skinny_u": [P, I, P, I, P, P, I, I, F, F, P, F, P, I, P, P],
+    "vlb_wgrad_skinny_u_multi": [P, I, P, I, I, I, P, P, P, P, F, F, F, P, I, P, P],
     "vlb_transpose16_scatter": [P, I, P],
     "vlb_wgrad_splits": [I],
     "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],

@@ -177,6 +177,28 @@ __device__ __forceinline__ void store_swiglu8(const GemmArgs& p, const f32x4& g0
   }
 }
 
+// bias / activation / residual of one fragment piece: lane holds C[m][n .. n+3]
+__device__ __forceinline__ bf16x4 w4_frag_value(const GemmArgs& p, f32x4 v, int m, int n) {
+  if (p.bias) {
+    const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+  }
+  if (p.act != VLB_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+  }
+  if (p.residual) {
+    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  return o;
+}
+
 // LDS image of a [rows][64] bf16 tile: 128-byte rows, 16-byte chunk c of row r lives at slot
 // c ^ ((r>>1)&7).  Two rows share one 256-byte bank row, so the 16 rows x 1 chunk column that a
 // ds_read_b128 lane group touches land on 16 distinct 16-byte slots: conflict-free.
@@ -294,28 +316,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= p.M) continue;
+    if (p.wide) {             // C rows 16-byte aligned: adjacent fragments paired into 16-byte stores (store_pair16)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * TN + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+      for (int j = 0; j < NT; j += 2) {
+        const int n = n0 + wn * TN + j * 16 + fq * 4;
+        store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value(p, acc[i][j], m, n), w4_frag_value(p, acc[i][j + 1], m, n + 16), fq);
       }
-      if (p.act != VLB_ACT_NONE) {
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * TN + j * 16 + fq * 4;
+        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value(p, acc[i][j], m, n);
       }
-      if (p.residual) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
     }
   }
 }
@@ -492,28 +504,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= p.M) continue;
+    if (p.wide) {             // C rows 16-byte aligned: adjacent fragments paired into 16-byte stores (store_pair16)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * TN + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
+      for (int j = 0; j < NT; j += 2) {
+        const int n = n0 + wn * TN + j * 16 + fq * 4;
+        store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value(p, acc[i][j], m, n), w4_frag_value(p, acc[i][j + 1], m, n + 16), fq);
       }
-      if (p.act != VLB_ACT_NONE) {
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * TN + j * 16 + fq * 4;
+        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value(p, acc[i][j], m, n);
       }
-      if (p.residual) {
-        const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
     }
   }
 }
@@ -642,26 +644,6 @@ __device__ __forceinline__ void w4_swiglu_bwd_value(const GemmArgs& p, const f32
     du[e] = (bf16)(v[e] * (g * sg));
     dg[e] = (bf16)(v[e] * u * (sg * (1.f + g * (1.f - sg))));
   }
-}
-__device__ __forceinline__ bf16x4 w4_frag_value(const GemmArgs& p, f32x4 v, int m, int n) {
-  if (p.bias) {
-    const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
-  }
-  if (p.act != VLB_ACT_NONE) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-  }
-  if (p.residual) {
-    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-  }
-  bf16x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-  return o;
 }
 // two adjacent fragments (columns n.. and n+16..), 16-byte stores
 __device__ __forceinline__ void w4_store_frag2(const GemmArgs& p, const f32x4& va, const f32x4& vb, int m, int n, int fq) {

@@ -218,11 +218,16 @@ __device__ __forceinline__ int xsw(int r) { return (r & 3) | (((r >> 3) & 1) << 
 // Bt [16, K] (row reads of the X image, MFMA rows = ranks), the four waves' partials meet in LDS and are stored as
 // upart[column block][row][16] fp32 - summed over column blocks by u_reduce_kernel.  This is LoRA backward's
 // u = s dy B riding on the dB^T = t^T dy pass, instead of a second sweep over dy.
+// WITH_U over several projections that share one dy = X (q|k|v, gate|up): column block c0 belongs to projection
+// j = #{col0[1..] <= c0}; its G tile is t[:, 16j..16j+16), its Bt is UProj::bt[j] ([16, n_j], n_j = col0[j+1] - col0[j]).
+// The slab / upart layouts do not change (they are indexed by the column of X), only the reduce kernel scatters.
+struct UProj { int col0[4]; const bf16* bt[3]; float* dW[3]; int n; };
+
 template <int G, bool WITH_U = false>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict__ Gm, int ldg, const bf16* __restrict__ X,
                                                          int ldx, float* __restrict__ ws, int M, int K,
                                                          int rows_per_split, uint32_t thresh, Seeds seeds,
-                                                         const bf16* __restrict__ Bt = nullptr, float* __restrict__ upart = nullptr) {
+                                                         UProj up = UProj{}, float* __restrict__ upart = nullptr) {
   constexpr int XT = WG_STEP * WG_COLS * 2;          // 16 KB
   constexpr int GT = WG_STEP * 16 * G * 2;           // 1 KB per group
   constexpr int UT = WITH_U ? 2 * 4 * 2 * 4 * 64 * 4 : 0;     // [parity][wave][row tile][reg][lane] fp32 = 16 KB
@@ -243,11 +248,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
   // u = X . Bt^T: this wave's 64 columns = two k-steps of 32; Bt fragments stay in registers for the whole block
   bf16x8 btf[2];
   if constexpr (WITH_U) {
+    const int pj = (c0 >= up.col0[1]) + (c0 >= up.col0[2]);            // block-uniform projection index
+    const int pc0 = up.col0[pj], pn = up.col0[pj + 1] - pc0;
+    const bf16* Bt = up.bt[pj];
+    Gm += 16 * pj;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int col = min(c0 + wave * 64 + 32 * ks + 8 * fq, K - 8);
-      btf[ks] = *reinterpret_cast<const bf16x8*>(Bt + (int64_t)fr * K + col);
-      if (c0 + wave * 64 + 32 * ks + 8 * fq >= K) btf[ks] = bf16x8{};
+      const int lc = c0 - pc0 + wave * 64 + 32 * ks + 8 * fq;          // column inside the projection
+      btf[ks] = *reinterpret_cast<const bf16x8*>(Bt + (int64_t)fr * pn + min(lc, pn - 8));
+      if (lc >= pn) btf[ks] = bf16x8{};
     }
   }
   float* ured = reinterpret_cast<float*>(smem + 2 * (XT + GT));
@@ -405,26 +414,33 @@ __global__ __launch_bounds__(256) void transpose16_scatter_kernel(const ScatterJ
   *reinterpret_cast<bf16x8*>(d + 8) = hi;
 }
 
-// One launch for both fixed-order sums of the fused dB/u pass: blocks [0, wblocks) reduce the dW slabs (grid-stride),
-// the rest compute u[m][r] (bf16, row stride ldu) = scale * sum over column blocks of upart[block][m][r].
-__global__ void wgrad_u_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int splits, int64_t nk, float alpha,
-                                      float beta, int wblocks, const float* __restrict__ upart, bf16* __restrict__ u, int ldu,
-                                      int M, int nblk, float scale) {
+// One launch for both fixed-order sums of the fused dB/u pass: blocks [0, wblocks) reduce the dW slabs (grid-stride) and
+// scatter them to the projections' [16, n_j] gradients, the rest compute u[m][16j + r] (bf16, row stride ldu) =
+// scale * sum over projection j's column blocks of upart[block][m][r].
+__global__ void wgrad_u_reduce_kernel(const float* __restrict__ ws, int splits, int K, float alpha, float beta, int wblocks,
+                                      const float* __restrict__ upart, bf16* __restrict__ u, int ldu, int M, float scale, UProj up) {
+  const int64_t nk = (int64_t)16 * K;
   if ((int)blockIdx.x < wblocks) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)wblocks * blockDim.x) {
       float s = 0.f;
 #pragma unroll 8
       for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * nk + i];          // loads independent: 8 in flight
-      dW[i] = alpha * s + (beta != 0.f ? beta * dW[i] : 0.f);
+      const int r = (int)(i / K), col = (int)(i - (int64_t)r * K);
+      const int pj = (col >= up.col0[1]) + (col >= up.col0[2]);
+      float* d = up.dW[pj] + (int64_t)r * (up.col0[pj + 1] - up.col0[pj]) + (col - up.col0[pj]);
+      *d = alpha * s + (beta != 0.f ? beta * *d : 0.f);
     }
     return;
   }
+  const int w = 16 * up.n;
   const int64_t i = (int64_t)(blockIdx.x - wblocks) * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)M * 16) return;
+  if (i >= (int64_t)M * w) return;
+  const int m = (int)(i / w), jr = (int)(i - (int64_t)m * w), pj = jr >> 4, r = jr & 15;
+  const int b0 = up.col0[pj] / WG_COLS, b1 = (up.col0[pj + 1] + WG_COLS - 1) / WG_COLS;      // (one projection: any K; several: multiples of 256)
   float v = 0.f;
 #pragma unroll 8
-  for (int b = 0; b < nblk; ++b) v += upart[(int64_t)b * M * 16 + i];
-  u[(i >> 4) * ldu + (i & 15)] = (bf16)(v * scale);
+  for (int b = b0; b < b1; ++b) v += upart[((int64_t)b * M + m) * 16 + r];
+  u[(int64_t)m * ldu + jr] = (bf16)(v * scale);
 }
 
 inline uint32_t lowbias32_host(uint32_t x) {
@@ -529,6 +545,32 @@ extern "C" int vlb_transpose16_scatter(const void* jobs, int n_jobs, void* strea
 
 extern "C" int64_t vlb_wgrad_u_ws_floats(int M, int K) { return (int64_t)((K + WG_COLS - 1) / WG_COLS) * M * 16; }
 
+static int wgrad_skinny_u_impl(const void* G, int ldg, const void* X, int ldx, int M, int K, int nproj, const int* cols,
+                               float* const* dW, const void* const* Bt, float* ws, float alpha, float beta, float u_scale, void* u,
+                               int ldu, float* u_ws, void* stream) {
+  UProj up{};
+  up.n = nproj;
+  int c = 0;
+  for (int j = 0; j < 4; ++j) up.col0[j] = 0x7fffffff;
+  for (int j = 0; j < nproj; ++j) { up.col0[j] = c; up.bt[j] = (const bf16*)Bt[j]; up.dW[j] = dW[j]; c += cols[j]; }
+  up.col0[nproj] = c;
+  hipStream_t st = as_stream(stream);
+  const int splits = vlb_wgrad_splits(M);
+  const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
+  const Seeds sd = make_seeds(nullptr, 1, M, K);
+  dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps,
+                     0u, sd, up, u_ws);
+  VLB_LAUNCH_CHECK();
+  const int64_t nk = (int64_t)16 * K;
+  int wblocks = (int)((nk + 255) / 256); if (wblocks > 1024) wblocks = 1024;
+  const int ublocks = (int)(((int64_t)M * 16 * nproj + 255) / 256);
+  hipLaunchKernelGGL(wgrad_u_reduce_kernel, dim3(wblocks + ublocks), dim3(256), 0, st, ws, splits, K, alpha, beta, wblocks,
+                     u_ws, (bf16*)u, ldu, M, u_scale, up);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
 extern "C" int vlb_wgrad_skinny_u(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int K,
                                   float alpha, float beta, const void* Bt, float u_scale, void* u, int ldu, float* u_ws,
                                   void* stream) {
@@ -536,19 +578,20 @@ extern "C" int vlb_wgrad_skinny_u(const void* G, int ldg, const void* X, int ldx
   VLB_REQUIRE(M > 0 && K >= 64 && K % 64 == 0 && ldx % 8 == 0 && ldg % 8 == 0 && ldu >= 16,
               "wgrad_skinny_u: bad shape M=%d K=%d", M, K);
   VLB_REQUIRE((((uintptr_t)G | (uintptr_t)X | (uintptr_t)Bt) % 16) == 0, "wgrad_skinny_u: operands must be 16-byte aligned");
-  hipStream_t st = as_stream(stream);
-  const int splits = vlb_wgrad_splits(M);
-  const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
-  const Seeds sd = make_seeds(nullptr, 1, M, K);
-  dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
-  hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps,
-                     0u, sd, (const bf16*)Bt, u_ws);
-  VLB_LAUNCH_CHECK();
-  const int64_t nk = (int64_t)16 * K;
-  int wblocks = (int)((nk + 255) / 256); if (wblocks > 1024) wblocks = 1024;
-  const int ublocks = (int)(((int64_t)M * 16 + 255) / 256);
-  hipLaunchKernelGGL(wgrad_u_reduce_kernel, dim3(wblocks + ublocks), dim3(256), 0, st, ws, dW, splits, nk, alpha, beta, wblocks,
-                     u_ws, (bf16*)u, ldu, M, (int)grid.x, u_scale);
-  VLB_LAUNCH_CHECK();
-  return VLB_OK;
+  return wgrad_skinny_u_impl(G, ldg, X, ldx, M, K, 1, &K, &dW, &Bt, ws, alpha, beta, u_scale, u, ldu, u_ws, stream);
+}
+
+extern "C" int vlb_wgrad_skinny_u_multi(const void* G, int ldg, const void* X, int ldx, int M, int nproj, const int* cols,
+                                        float* const* dW, const void* const* Bt, float* ws, float alpha, float beta, float u_scale,
+                                        void* u, int ldu, float* u_ws, void* stream) {
+  VLB_REQUIRE(G && X && cols && dW && Bt && ws && u && u_ws && nproj >= 1 && nproj <= 3, "wgrad_skinny_u_multi: bad arguments (1..3 projections)");
+  int K = 0;
+  for (int j = 0; j < nproj; ++j) {
+    VLB_REQUIRE(dW[j] && Bt[j] && cols[j] > 0 && cols[j] % WG_COLS == 0 && ((uintptr_t)Bt[j] % 16) == 0,
+                "wgrad_skinny_u_multi: projection %d: columns must be a multiple of %d, Bt 16-byte aligned", j, WG_COLS);
+    K += cols[j];
+  }
+  VLB_REQUIRE(M > 0 && ldx % 8 == 0 && ldx >= K && ldg % 8 == 0 && ldg >= 16 * nproj && ldu >= 16 * nproj, "wgrad_skinny_u_multi: bad leading dimensions");
+  VLB_REQUIRE((((uintptr_t)G | (uintptr_t)X) % 16) == 0, "wgrad_skinny_u_multi: operands must be 16-byte aligned");
+  return wgrad_skinny_u_impl(G, ldg, X, ldx, M, K, nproj, cols, dW, Bt, ws, alpha, beta, u_scale, u, ldu, u_ws, stream);
 }

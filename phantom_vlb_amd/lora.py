@@ -28,6 +28,7 @@ from .geometry import Geometry
 BF16 = torch.bfloat16
 PAD = 64  # adapter rank columns padded to one GEMM K-tile
 FUSE_SWIGLU_BWD = True      # SwiGLU backward in the epilogue of the down projection's dgrad GEMM (A/B switch)
+MERGE_DB_U = True           # one dB^T / u sweep for the projections sharing a dy (q|k|v, gate|up) instead of one each (A/B switch)
 
 
 def _stream():
@@ -57,6 +58,17 @@ def wgrad_skinny_u(G, X, dW, ws, Bt, u_scale, u_out, u_ws, alpha=1.0, beta=0.0):
     check(lib.vlb_wgrad_skinny_u(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), ws.data_ptr(), M, K,
                                  alpha, beta, Bt.data_ptr(), u_scale, u_out.data_ptr(), u_out.stride(0), u_ws.data_ptr(),
                                  _stream()), "vlb_wgrad_skinny_u")
+
+
+def wgrad_skinny_u_multi(G, X, cols, dWs, Bts, ws, u_scale, u_out, u_ws, alpha=1.0, beta=0.0):
+    """The dB^T / u pass of ``wgrad_skinny_u`` for the projections sharing X = dy [M, sum(cols)] in one sweep: projection j
+    reads t = G[:, 16j:16j+16], writes dWs[j] [16, cols[j]] fp32 and u_out[:, 16j:16j+16]."""
+    M = X.shape[0]
+    n = len(cols)
+    check(lib.vlb_wgrad_skinny_u_multi(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), M, n, (ctypes.c_int * n)(*cols),
+                                       (ctypes.c_void_p * n)(*[t.data_ptr() for t in dWs]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in Bts]),
+                                       ws.data_ptr(), alpha, beta, u_scale, u_out.data_ptr(), u_out.stride(0), u_ws.data_ptr(), _stream()),
+          "vlb_wgrad_skinny_u_multi")
 
 
 def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seeds=None):
@@ -230,8 +242,9 @@ class LoraState:
         if self._ws is None or self._ws["cap"] < M:          # grow-only: packed batches change M every step
             g, d = self.g, self.dev
             kmax = max(g.ff, g.dim, g.heads * g.head_dim)
+            kgrp = max(2 * g.ff, (g.heads + 2 * g.kv_heads) * g.head_dim)      # widest dy a group's projections share
             self._ws = dict(cap=M, wg=torch.empty(lib.vlb_wgrad_splits(M) * 48 * kmax, dtype=torch.float32, device=d),
-                            uws=torch.empty(lib.vlb_wgrad_u_ws_floats(M, kmax), dtype=torch.float32, device=d),
+                            uws=torch.empty(lib.vlb_wgrad_u_ws_floats(M, kgrp), dtype=torch.float32, device=d),
                             u_full=torch.zeros(M, self._rpad_max(), dtype=BF16, device=d))
         self._ws["u"] = self._ws["u_full"][:M]
         return self._ws
@@ -346,7 +359,13 @@ class LoraState:
         col = 0
         u = u[:, :lay["Rpad"]]
         rp = self.rp
-        for j, tname in enumerate(lay["targets"]):
+        names = [f"model.layers.{li}.{tname}" for tname in lay["targets"]]
+        cols = [self.out_dims[tname] for tname in lay["targets"]]
+        multi = MERGE_DB_U and self.c == 1 and len(cols) > 1 and all(n % 256 == 0 for n in cols) and dy.shape[1] == sum(cols)
+        if multi:           # q|k|v and gate|up: one sweep over the shared dy for every projection's dB^T and u
+            wgrad_skinny_u_multi(t, dy, cols, [self.grads[f"{pre}.lora_B.weight"] for pre in names],
+                                 [self.bt[f"{pre}.lora_B.weight"] for pre in names], ws["wg"], self.scale, u, ws["uws"])
+        for j, tname in enumerate(() if multi else lay["targets"]):
             n = self.out_dims[tname]
             pre = f"model.layers.{li}.{tname}"
             dyj = dy[:, col:col + n]

@@ -124,6 +124,36 @@ def test_wgrad_skinny(dev, M, N, K, p):
     assert rel_err(dW, 2 * ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,cols", [(300, [256]), (1000, [512, 256, 256]), (5861, [4096, 1024, 1024]), (2500, [1024, 1024])])
+def test_wgrad_skinny_u_single_and_multi(dev, M, cols):
+    """dB^T = t^T dY and u = s dY B in one sweep over dY: per projection (vlb_wgrad_skinny_u) and for the projections that share
+    one dY in a single launch (vlb_wgrad_skinny_u_multi) - both against fp32 torch, and against each other."""
+    from phantom_vlb_amd._lib import lib
+    from phantom_vlb_amd.lora import wgrad_skinny_u, wgrad_skinny_u_multi
+    n, K = len(cols), sum(cols)
+    t = torch.zeros(M, 64, dtype=BF, device=dev)
+    t[:, :16 * n] = _r(M, 16 * n, dev=dev)
+    dy = _r(M, K + 64, dev=dev, seed=2)[:, :K]                # strided view, as dqkv's column slices are
+    bts = [_r(16, c, dev=dev, scale=0.3, seed=10 + j) for j, c in enumerate(cols)]
+    ws = torch.empty(lib.vlb_wgrad_splits(M) * 16 * K, dtype=torch.float32, device=dev)
+    uws = torch.empty(lib.vlb_wgrad_u_ws_floats(M, K), dtype=torch.float32, device=dev)
+    dws = [torch.full((16, c), 3.0, dtype=torch.float32, device=dev) for c in cols]
+    u = torch.zeros(M, 64, dtype=BF, device=dev)
+    wgrad_skinny_u_multi(t, dy, cols, dws, bts, ws, 2.0, u, uws)
+    c0 = 0
+    for j, c in enumerate(cols):
+        dyj = dy[:, c0:c0 + c]
+        ref_dw = t[:, 16 * j:16 * j + 16].float().t() @ dyj.float()
+        ref_u = 2.0 * dyj.float() @ bts[j].float().t()
+        assert rel_err(dws[j], ref_dw) < 2e-3, j
+        assert rel_err(u[:, 16 * j:16 * j + 16], ref_u) < 1e-2, j
+        dw1, u1 = torch.empty(16, c, dtype=torch.float32, device=dev), torch.zeros(M, 16, dtype=BF, device=dev)
+        wgrad_skinny_u(t[:, 16 * j:16 * j + 16], dyj, dw1, ws, bts[j], 2.0, u1, uws)
+        assert torch.equal(dw1, dws[j]) and torch.equal(u1, u[:, 16 * j:16 * j + 16]), j       # same sums in the same order
+        c0 += c
+    assert u[:, 16 * n:].abs().max() == 0
+
+
 @pytest.mark.parametrize("B,S,Hq,Hkv,causal,masked", [(2, 128, 4, 1, True, True), (1, 300, 8, 2, True, False),
                                                      (2, 96, 2, 2, False, False), (1, 1024, 4, 1, True, True)])
 def test_attention_bwd(dev, B, S, Hq, Hkv, causal, masked):
