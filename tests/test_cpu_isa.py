@@ -17,8 +17,10 @@ def test_four_wave_gemm_k_loops_stay_in_registers(tmp_path):
     import audit_gemm_isa as A
     import subprocess
     out = str(tmp_path / "gemm.s")
-    subprocess.run([A.HIPCC if os.path.exists(A.HIPCC) else shutil.which("hipcc"), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
-                    "-Wno-unused-function", "-S", "--cuda-device-only", os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out],
+    mk = open(os.path.join(ROOT, "phantom_vlb_amd", "csrc", "Makefile")).read()
+    assert "-pragma-unroll-threshold=100000" in mk and "-pragma-unroll-threshold=100000" in A.FLAGS      # audit what the Makefile builds
+    subprocess.run([A.HIPCC if os.path.exists(A.HIPCC) else shutil.which("hipcc")] + A.FLAGS +
+                   ["-S", "--cuda-device-only", os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     report, bad = A.audit(out)
     assert len(report) >= 8, report

@@ -17,6 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-mllvm", "-pragma-unroll-threshold=100000"]      # = csrc/Makefile (FLAGS + GEMM_FLAGS)
 
 
 def k_loops(body):
@@ -25,7 +26,7 @@ def k_loops(body):
         m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < k:
             seg = body[labels[m.group(1)]:k + 1]
-            if any("v_mfma" in x for x in seg):
+            if any("v_mfma" in x for x in seg) and any("global_load_lds" in x for x in seg):      # the K loop (epilogues hold MFMAs too)
                 yield seg
 
 
@@ -60,7 +61,7 @@ def audit(asm_path):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "gemm.s")
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-function", "-S", "--cuda-device-only",
+        subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only",
                         os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         report, bad = audit(out)
     print("\n".join(report))
