@@ -261,9 +261,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
   }
   float* ured = reinterpret_cast<float*>(smem + 2 * (XT + GT));
 
-  // staging: X piece i of this wave = rows 2*(4i+wave) + (lane>>5); 16-byte position pc = lane & 31
-  auto stage = [&](int buf, int m0) {
+  // staging: X piece i of this wave = rows 2*(4i+wave) + (lane>>5); 16-byte position pc = lane & 31.  The G tile (32 rows x
+  // 16G columns, at most one 16-byte chunk per thread) goes through registers: its load is ISSUED in front of the X pieces
+  // and written to LDS only after the current step's math (g_store) - a wait for it in between would also wait for the
+  // LDS-DMA pieces behind it (vmcnt counts in order) and serialise the next tile's latency with this tile's compute.
+  const int g_r = tid / (2 * G), g_ch = tid % (2 * G);
+  const bool g_mine = tid < WG_STEP * 2 * G;
+  auto stage = [&](int buf, int m0, bf16x8& gv) {
     char* xb = smem + buf * (XT + GT);
+    gv = bf16x8{};                               // rows beyond the split are zero: they contribute nothing
+    if (g_mine && m0 + g_r < r1) gv = *reinterpret_cast<const bf16x8*>(Gm + (int64_t)(m0 + g_r) * ldg + g_ch * 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int piece = 4 * i + wave, r = 2 * piece + (lane >> 5), pc = lane & 31;
@@ -272,26 +279,24 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       const int col = min(c0 + chunk * 8, K - 8);
       glds16_l(X + (int64_t)m * ldx + col, xb + piece * 1024);
     }
-    // G tile: 32 rows x 16G columns, 16-byte chunks; zero rows beyond the split so they contribute nothing
-    for (int i = tid; i < WG_STEP * 2 * G; i += 256) {
-      const int r = i / (2 * G), ch = i % (2 * G);
-      bf16x8 v = bf16x8{};
-      if (m0 + r < r1) v = *reinterpret_cast<const bf16x8*>(Gm + (int64_t)(m0 + r) * ldg + ch * 8);
-      *reinterpret_cast<bf16x8*>(xb + XT + r * 32 * G + ch * 16) = v;
-    }
+  };
+  auto g_store = [&](int buf, const bf16x8& gv) {
+    if (g_mine) *reinterpret_cast<bf16x8*>(smem + buf * (XT + GT) + XT + g_r * 32 * G + g_ch * 16) = gv;
   };
 
   const int nsteps = (r1 - r0 + WG_STEP - 1) / WG_STEP;
-  if (nsteps > 0) stage(0, r0);
+  bf16x8 gnext;
+  if (nsteps > 0) { stage(0, r0, gnext); g_store(0, gnext); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1, m0 = r0 + st * WG_STEP;
-    if (st + 1 < nsteps) stage(cur ^ 1, m0 + WG_STEP);
     const char* xb = smem + cur * (XT + GT);
     const char* gb = xb + XT;
+    // ---- 1. every fragment of the current tile into registers (the compiler orders LDS accesses behind in-flight LDS-DMA
+    // with vmcnt(0), so nothing may touch LDS between the issue of the next tile and the end of this step's math)
     // A' fragments (G^T): rows 8fq + {0..3} and + 4, columns 16g + 4tp
-    bf16x8 af[G];
+    bf16x8 af[G], xf[4];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(gb + (8 * fq + tq) * 32 * G + (16 * g + 4 * tp) * 2));
@@ -307,11 +312,32 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       const int pb = (((colb >> 4) ^ xsw(rb)) << 5) + ((4 * tp) << 1);
       const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + ra * 512 + pa));
       const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + rb * 512 + pb));
-      const bf16x8 xf = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      const int col = c0 + colb + fr;
+      xf[n] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+    bf16x8 xr[2][2];
+    if constexpr (WITH_U) {
+      // row reads of the X image: source chunk c (8 columns) of row r sits at 16-byte position
+      // (((c>>1) ^ xsw(r)) << 1) | (c&1) of the row's 512 bytes
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r = 16 * t + fr, c = wave * 8 + 4 * ks + fq;       // 16-byte source chunk inside the 256-column tile
+          const int pc = (((c >> 1) ^ xsw(r)) << 1) | (c & 1);
+          xr[t][ks] = *reinterpret_cast<const bf16x8*>(xb + r * 512 + pc * 16);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. the next tile goes in flight under this tile's math
+    if (st + 1 < nsteps) stage(cur ^ 1, m0 + WG_STEP, gnext);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. math
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int col = c0 + wave * 64 + n * 16 + fr;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        bf16x8 xm = xf;
+        bf16x8 xm = xf[n];
         if (thresh != 0) {
           // lanes fr and fr^1 hold the two columns of one hashed pair: the even lane hashes rows 0..3, the
           // odd lane rows 4..7, and they swap results (quad_perm [1,0,3,2]) - half the hashes per lane
@@ -333,24 +359,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       }
     }
     if constexpr (WITH_U) {
-      // row reads of the X image: source chunk c (8 columns) of row r sits at 16-byte position
-      // (((c>>1) ^ xsw(r)) << 1) | (c&1) of the row's 512 bytes
       float* mine = ured + ((cur * 4 + wave) * 2) * 4 * 64;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 ua = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int r = 16 * t + fr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int c = wave * 8 + 4 * ks + fq;                 // 16-byte source chunk inside the 256-column tile
-          const int pc = (((c >> 1) ^ xsw(r)) << 1) | (c & 1);
-          const bf16x8 xr = *reinterpret_cast<const bf16x8*>(xb + r * 512 + pc * 16);
-          ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btf[ks], xr, ua, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 2; ++ks) ua = __builtin_amdgcn_mfma_f32_16x16x32_bf16(btf[ks], xr[t][ks], ua, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) mine[(t * 4 + e) * 64 + lane] = ua[e];
       }
     }
+    if (st + 1 < nsteps) g_store(cur ^ 1, gnext);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (WITH_U) {
