@@ -9,7 +9,7 @@
 A "step" = forward through CLIP tower + STC connector + splice + 32 Mistral layers (+LoRA) + brain head,
 backward through head and decoder (LoRA A/B gradients), global-norm clip, AdamW, cosine LR - all on
 libvlb HIP kernels, inputs resident in HBM.  One JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
-the 256x256 MFMA GEMM on the gate/up projection, timed with HIP events on its own stream inside the
+the 256x256 MFMA GEMM call of the gate/up projection, timed with HIP events on its own stream inside the
 timed region) and `cpu_baseline` (the oracle on the host cores, bounded sample, N=1 only).
 """
 from __future__ import annotations
@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
 # L2->fabric bytes of ONE gate/up GEMM call, measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE
 # passes, gfx950 2x read correction; tools/profile_tables.py traffic).  Only valid for that shape.
-GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 2.610e9,     # default (LoRA, packed rows), main launch + split-K tail + reduce: profiles/r02_gemm_gateup_hbm_traffic_lora.csv
+GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 3.150e9,     # default (LoRA, packed rows; GEMM + SwiGLU + saved pre-activations), main launch + split-K tail + reduce: profiles/r02_gemm_gateup_hbm_traffic_lora.csv
                         (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows, main launch: profiles/r01_gemm_gateup_hbm_traffic_frozen_w4.csv
                         (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: profiles/r01_gemm_gateup_hbm_traffic.csv
 # algorithmic TFLOP per clip
@@ -268,11 +268,13 @@ def main():
                        "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense, 1),
                        "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + the split-K launches of its partial last wave "
-                         f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_bf16 call", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                         f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per "
+                         + ("vlb_gemm_swiglu_save call (epilogue: + LoRA pair, SwiGLU, saved pre-activations; FLOPs counted: the base GEMM only)" if lora
+                            else "vlb_gemm_bf16 call"), "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
                          "traffic_note": "L2->fabric bytes per call from rocprofv3 PMC passes (profiles/r02_gemm_gateup_hbm_traffic_lora.csv; frozen shapes: r01_*); "
-                         + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN:.3e} (A | t, W | B, C [M,N] bf16)" if lora else
+                         + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN + 1.0 * pM * pN:.3e} (A | t, W | B, saved [gate|up] [M,N] and silu(gate)*up [M,N/2], bf16)" if lora else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},

@@ -152,15 +152,15 @@ def traffic(dfetch, dwrite, out):
     fm, ft = res["FETCH_SIZE"][2], res["FETCH_SIZE"][3]
     wm, wt = res["WRITE_SIZE"][2], res["WRITE_SIZE"][3]
     total = (2 * (fm + ft) + wm + wt) * 1024
-    alg = 2.0 * (M * (E + 64) + 2 * FF * (E + 64)) + 2.0 * M * 2 * FF
+    alg = 2.0 * (M * (E + 64) + 2 * FF * (E + 64)) + 2.0 * M * 2 * FF + 2.0 * M * FF      # A|t, W|B, saved [gate|up] [M,2FF], h = silu(gate)*up [M,FF]
     with open(out, "w") as o:
         o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (default LoRA workload, packed rows)\n")
-        o.write("# one gate/up GEMM CALL = main gemm_w4_kernel launch (10 full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
+        o.write("# one gate/up GEMM CALL (vlb_gemm_swiglu_save: GEMM + SwiGLU + saved pre-activations) = main gemm_w4_kernel launch (10 full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
         o.write("# gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
         o.write("counter,main_grid_threads,calls,main_mean_kb,tail_mean_kb\n")
         for c, (g, n, a, b) in res.items():
             o.write(f"{c},{g},{n},{a:.1f},{b:.1f}\n")
-        o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} (A|t + W|B + C [M,N] bf16); ratio {total / alg:.2f}\n")
+        o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} (A|t + W|B + saved [gate|up] [M,N] + h [M,N/2], bf16); ratio {total / alg:.2f}\n")
     print(open(out).read())
 
 
