@@ -191,8 +191,11 @@ class DevicePrefetcher:
     uploaded by the step itself).  Device tensors are tied to the consumer stream with ``record_stream`` so
     the caching allocator cannot recycle them while a kernel still reads them."""
 
-    def __init__(self, loader, device, keep_on_host=("language", "padvals")):
+    def __init__(self, loader, device, keep_on_host=("language", "padvals"), on_staged=None):
+        """``on_staged(batch, event)``: called for every batch right after its copies were enqueued (event = copies done),
+        i.e. one step before the batch is handed over - VLBLitModule.prefetch_vision hooks in here."""
         self.loader, self.device, self.keep = loader, torch.device(device), tuple(keep_on_host)
+        self.on_staged = on_staged
         self.sampler = getattr(loader, "sampler", None)
         self.stream = torch.cuda.Stream(device=self.device)
 
@@ -205,6 +208,8 @@ class DevicePrefetcher:
             for k, v in batch.items():
                 out[k] = v if (k in self.keep or not torch.is_tensor(v)) else v.to(self.device, non_blocking=True)
             ev.record(self.stream)
+        if self.on_staged is not None:
+            self.on_staged(out, ev)
         return out, ev
 
     def __iter__(self):

@@ -279,6 +279,17 @@ class VLBLitModule(_Base):
         pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout, ids_host=ids_host)
         return pred, y, self._loss_terms
 
+    def prefetch_vision(self, batch, ready_event=None):
+        """Start the frozen vision side (CLIP tower + STC connector) of a FUTURE batch on a side stream, so that it runs under
+        the current step's decoder work; the step that later receives this batch picks the result up (Backbone.video_tokens).
+        No-op when the connector trains (full fine-tune).  Called by DevicePrefetcher for batch i+1 before step i is issued."""
+        if self.full is not None or "vision" not in batch or not batch["vision"].is_cuda:
+            return
+        # Deferred: the next training_step launches it right behind its forward pass, so the side stream runs under the BACKWARD
+        # pass (the skinny LoRA kernels and the GEMM tails leave CUs idle there; the forward's GEMMs do not, and the bench's
+        # dominant-kernel timing stays undisturbed).  A batch whose own step comes first is computed in line by that step.
+        self.backbone.defer_video_tokens(batch["vision"], ready_event)
+
     def training_step(self, batch):
         """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
         self.train(True)
@@ -286,6 +297,7 @@ class VLBLitModule(_Base):
         if self.lora is not None:
             self.lora.rank = self.rank
         pred, y, terms = self._common_step(batch, train=True)
+        self.backbone.launch_deferred_video_tokens()         # a future batch's frozen vision side: behind this forward, under this backward
         need_dh = self.lora is not None or self.full is not None
         inv_world = 1.0 / self.world_size
         dh = self.head.backward(need_dhidden=need_dh, loss_scale=inv_world, l2_scale=inv_world)
@@ -309,6 +321,7 @@ class VLBLitModule(_Base):
         was = self.training
         self.train(False)
         pred, y, terms = self._common_step(batch, train=False)
+        self.backbone.launch_deferred_video_tokens()
         self.train(was)
         loss = terms[2].clone()
         self.log("val/brain_loss", loss)

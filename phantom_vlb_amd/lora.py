@@ -296,8 +296,7 @@ class LoraState:
         ``layout``: packed RowLayout (rows without the clips' padded tails) or None for dense [B,S]."""
         g = self.g
         B = vision_f32.shape[0]
-        pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
-        vid = backbone.connector(backbone.vision_tower(pix), B)          # frozen: no activations kept
+        vid = backbone.video_tokens(vision_f32)          # frozen: no activations kept; may have been started one step ahead
         x, key_mask = backbone.splice(ids, vid, layout)
         return self.decoder_forward(backbone, x, key_mask, B, layout, train=train)
 

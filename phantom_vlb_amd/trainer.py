@@ -222,8 +222,10 @@ class Trainer:
         val_loader = datamodule.val_dataloader()
         if torch.cuda.is_available():        # overlap the next batch's host->device copy with the current step
             from .datamodule import DevicePrefetcher
-            train_loader = DevicePrefetcher(train_loader, model.device)
-            val_loader = DevicePrefetcher(val_loader, model.device)
+            # ... and start the frozen vision side of batch i+1 on a side stream under step i (VLBLitModule.prefetch_vision)
+            hook = getattr(model, "prefetch_vision", None)
+            train_loader = DevicePrefetcher(train_loader, model.device, on_staged=hook)
+            val_loader = DevicePrefetcher(val_loader, model.device, on_staged=hook)
         n_batches = len(train_loader)
         val_every = max(1, int(n_batches * self.val_check_interval)) if self.val_check_interval <= 1 else int(self.val_check_interval)
         t0 = time.time()

@@ -116,3 +116,44 @@ def test_validation_step_contract(mini_frozen):
     assert set(out) == {"loss", "brain_preds", "brain_vals"}
     assert out["brain_preds"].shape == (4, 128) and out["brain_vals"].shape == (4, 128)
     assert "val/brain_loss" in m.logged
+
+
+def test_vision_prefetch_is_bit_identical_and_consumed_once(dev):
+    """Backbone.prefetch_video_tokens / video_tokens: the frozen vision side computed one step ahead on the side stream gives
+    the very same bits as the in-line computation, is consumed exactly once, and a tensor that was modified in place since the
+    prefetch (version counter) is recomputed in line.  Whole training steps with and without the prefetch give the same loss."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=1234))
+    batch = {k: (v.to(dev) if torch.is_tensor(v) and k not in ("language", "padvals") else v) for k, v in O.synthetic_batch(g, 4, seed=3).items()}
+    cfg = VLBLitModuleConfig(model_path="none", freeze_backbone=True, use_lora=False, lora_r=None, lora_alpha=None, lora_dropout=None,
+                             dropout_rate=0.0, num_target=128, l2_lambda=1e-3, lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2,
+                             lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini")
+    m = VLBLitModule(cfg)
+    m.configure_model(state_dict=p, head_state=p)
+    m.configure_optimizers()
+    bb = m.backbone
+    inline = bb.video_tokens(batch["vision"]).clone()
+    bb.prefetch_video_tokens(batch["vision"])
+    assert len(bb._vis_queue) == 1
+    got = bb.video_tokens(batch["vision"])
+    assert len(bb._vis_queue) == 0 and torch.equal(got, inline)
+    bb.prefetch_video_tokens(batch["vision"])
+    batch["vision"].mul_(1.0)                               # in-place touch: the queued entry no longer describes this tensor
+    again = bb.video_tokens(batch["vision"])
+    assert len(bb._vis_queue) == 1 and torch.equal(again, inline)
+    bb._vis_queue.clear()
+    l0 = float(m.training_step(batch))
+    m.prefetch_vision(batch)                                # deferred; its own step comes first -> computed in line, once
+    assert len(bb._vis_pending) == 1 and not bb._vis_queue
+    l1 = float(m.training_step(batch))
+    assert not bb._vis_pending and not bb._vis_queue
+    m.prefetch_vision(batch)                                # the bench / Trainer pattern: register batch i+1, run step i
+    m.prefetch_vision(batch)
+    l2 = float(m.training_step(batch))                      # consumes the first registration in line, launches the second behind its forward
+    assert not bb._vis_pending and len(bb._vis_queue) == 1
+    l3 = float(m.training_step(batch))                      # picks the prefetched features up
+    torch.cuda.synchronize()
+    assert l0 == l1 == l2 == l3 and len(bb._vis_queue) == 0
