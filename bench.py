@@ -214,8 +214,8 @@ def main():
     # Software pipelining across steps, as Trainer.fit's DevicePrefetcher does it: the frozen vision side (CLIP tower + STC
     # connector) of the NEXT step's batch is enqueued on a side stream before this step's decoder work and picked up by the
     # next training_step.  Every step computes it exactly once for one batch (nothing is cached: the queue entry is consumed);
-    # not available when the connector trains (--workload full).  VLB_BENCH_VISION_PREFETCH=0 keeps everything on one stream.
-    pipelined = not full and os.environ.get("VLB_BENCH_VISION_PREFETCH", "1") == "1"
+    # with --workload full only the CLIP tower runs ahead (the connector trains).  VLB_BENCH_VISION_PREFETCH=0 keeps everything on one stream.
+    pipelined = os.environ.get("VLB_BENCH_VISION_PREFETCH", "1") == "1"
     if pipelined:
         m.prefetch_vision(batch)              # the first step's features
 
@@ -270,7 +270,7 @@ def main():
                                       + ("sharded 1/N per layer, all-gathered one layer ahead (fsdp.yaml FULL_SHARD equivalent)"
                                          if a.shard_frozen else "replicated (--shard-frozen for the fsdp.yaml-equivalent layout)"),
                        "comm": comm_name, "sharded_frozen_variant": None,
-                       "vision_prefetch": ("CLIP tower + connector of step i+1 run on a side stream under step i's decoder work (as Trainer.fit's "
+                       "vision_prefetch": (("CLIP tower" if full else "CLIP tower + connector") + " of step i+1 run on a side stream under step i's backward pass (as Trainer.fit's "
                                            "DevicePrefetcher does); each step computes them once, nothing is reused") if pipelined else "off",
                        "loss": round(float(loss), 6),
                        "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),

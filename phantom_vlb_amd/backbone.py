@@ -365,9 +365,15 @@ class Backbone:
     def _vision_key(vision_f32):
         return (vision_f32.data_ptr(), tuple(vision_f32.shape), vision_f32._version)
 
-    def prefetch_video_tokens(self, vision_f32, ready_event=None):
-        """Enqueue connector(vision_tower(pixels)) for this batch on the side stream.  ``ready_event``: recorded after the
-        pixels landed in HBM (DevicePrefetcher's copy); without it the side stream waits for the current stream."""
+    def _vision_compute(self, vision_f32, tower_only):
+        g, B = self.g, vision_f32.shape[0]
+        feats = self.vision_tower(vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size))
+        return feats if tower_only else self.connector(feats, B)
+
+    def prefetch_video_tokens(self, vision_f32, ready_event=None, tower_only=False):
+        """Enqueue connector(vision_tower(pixels)) - or, ``tower_only`` (full fine-tune: the connector trains), the tower's
+        output alone - for this batch on the side stream.  ``ready_event``: recorded after the pixels landed in HBM
+        (DevicePrefetcher's copy); without it the side stream waits for the current stream."""
         dev = self.w.dev
         if getattr(self, "_vis_stream", None) is None:
             self._vis_stream, self._vis_queue = torch.cuda.Stream(device=dev), []
@@ -376,35 +382,33 @@ class Backbone:
             st.wait_event(ready_event)
         else:
             st.wait_stream(torch.cuda.current_stream(dev))
-        g, B = self.g, vision_f32.shape[0]
         with torch.cuda.stream(st):
-            pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
-            vid = self.connector(self.vision_tower(pix), B)
+            vid = self._vision_compute(vision_f32, tower_only)
             ev = torch.cuda.Event()
             ev.record(st)
         vision_f32.record_stream(st)
-        self._vis_queue.append((self._vision_key(vision_f32), vid, ev))
+        self._vis_queue.append(((self._vision_key(vision_f32), tower_only), vid, ev))
         del self._vis_queue[:-4]                      # never more than a few batches ahead
 
-    def defer_video_tokens(self, vision_f32, ready_event=None):
+    def defer_video_tokens(self, vision_f32, ready_event=None, tower_only=False):
         """Register a future batch; launch_deferred_video_tokens() (called by the step functions right behind their forward
         pass) enqueues it on the side stream."""
         if getattr(self, "_vis_pending", None) is None:
             self._vis_pending = []
-        self._vis_pending.append((self._vision_key(vision_f32), vision_f32, ready_event))
+        self._vis_pending.append(((self._vision_key(vision_f32), tower_only), vision_f32, ready_event))
         del self._vis_pending[:-4]
 
     def launch_deferred_video_tokens(self):
         pend, self._vis_pending = getattr(self, "_vis_pending", None) or [], []
         for key, vis, ev in pend:
-            if key == self._vision_key(vis):          # still the tensor that was registered
-                self.prefetch_video_tokens(vis, ev)
+            if key[0] == self._vision_key(vis):       # still the tensor that was registered
+                self.prefetch_video_tokens(vis, ev, tower_only=key[1])
 
-    def video_tokens(self, vision_f32):
-        """connector(vision_tower(pixels)) [B, Nv, dim] - computed here, or taken from prefetch_video_tokens() when that ran
-        for this very tensor (same storage, shape and version counter)."""
+    def video_tokens(self, vision_f32, tower_only=False):
+        """connector(vision_tower(pixels)) [B, Nv, dim] (``tower_only``: the tower's tokens) - computed here, or taken from
+        prefetch_video_tokens() when that ran for this very tensor (same storage, shape and version counter)."""
         q = getattr(self, "_vis_queue", None)
-        key = self._vision_key(vision_f32)
+        key = (self._vision_key(vision_f32), tower_only)
         if q:
             for i, (k, vid, ev) in enumerate(q):
                 if k == key:
@@ -421,9 +425,7 @@ class Backbone:
                     if ev is not None:
                         torch.cuda.current_stream(self.w.dev).wait_event(ev)
                     break
-        g, B = self.g, vision_f32.shape[0]
-        pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
-        return self.connector(self.vision_tower(pix), B)
+        return self._vision_compute(vision_f32, tower_only)
 
     def forward(self, vision_f32, ids, stages=None, layout=None):
         """vision fp32 [B,T,3,H,W], ids int64 [B,L] -> hidden bf16 [rows, dim], key_mask uint8.

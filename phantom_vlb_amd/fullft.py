@@ -326,8 +326,7 @@ class FullFineTune:
     def forward(self, vision_f32, ids, layout=None, ids_host=None):
         g, bb, w = self.g, self.bb, self.w
         B = vision_f32.shape[0]
-        pix = vision_f32.reshape(B * g.num_frames, 3, g.image_size, g.image_size)
-        vid = self.connector_forward(bb.vision_tower(pix), B)          # tower frozen: nothing kept
+        vid = self.connector_forward(bb.video_tokens(vision_f32, tower_only=True), B)     # tower frozen: nothing kept; may have run one step ahead
         x, key_mask = bb.splice(ids, vid, layout)
         self._ids_host = ids_host if ids_host is not None else ids.cpu()
         S = g.max_len

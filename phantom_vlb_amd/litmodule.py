@@ -282,13 +282,14 @@ class VLBLitModule(_Base):
     def prefetch_vision(self, batch, ready_event=None):
         """Start the frozen vision side (CLIP tower + STC connector) of a FUTURE batch on a side stream, so that it runs under
         the current step's decoder work; the step that later receives this batch picks the result up (Backbone.video_tokens).
-        No-op when the connector trains (full fine-tune).  Called by DevicePrefetcher for batch i+1 before step i is issued."""
-        if self.full is not None or "vision" not in batch or not batch["vision"].is_cuda:
+        Full fine-tune: the connector trains, so only the CLIP tower runs ahead.  Called by DevicePrefetcher for batch i+1
+        before step i is issued."""
+        if "vision" not in batch or not batch["vision"].is_cuda:
             return
         # Deferred: the next training_step launches it right behind its forward pass, so the side stream runs under the BACKWARD
         # pass (the skinny LoRA kernels and the GEMM tails leave CUs idle there; the forward's GEMMs do not, and the bench's
         # dominant-kernel timing stays undisturbed).  A batch whose own step comes first is computed in line by that step.
-        self.backbone.defer_video_tokens(batch["vision"], ready_event)
+        self.backbone.defer_video_tokens(batch["vision"], ready_event, tower_only=self.full is not None)
 
     def training_step(self, batch):
         """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
