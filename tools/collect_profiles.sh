@@ -6,7 +6,10 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pf && mkdir -p gpurun_out/pf
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/lora -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/pf/lora.log 2>&1
-python3 tools/profile_tables.py stats gpurun_out/pf/lora 10 r02_bench_lora7b > gpurun_out/pf/lora_tables.log 2>&1
+python3 tools/profile_tables.py stats gpurun_out/pf/lora 10 r02_bench_lora7b "default command: the next step's vision side runs on a side stream under the backward pass, so kernel durations overlap (their sum exceeds the step time) and overlapped kernels read slower than alone" > gpurun_out/pf/lora_tables.log 2>&1
+# the same step with everything on one stream: clean per-kernel durations for the kernel split
+VLB_BENCH_VISION_PREFETCH=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/lora_serial -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/pf/lora_serial.log 2>&1
+python3 tools/profile_tables.py stats gpurun_out/pf/lora_serial 10 r02_bench_lora7b_serial "VLB_BENCH_VISION_PREFETCH=0: one stream, no overlap" > gpurun_out/pf/lora_serial_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pf/sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/sq.log 2>&1
 python3 tools/profile_tables.py sq gpurun_out/pf/sq profiles/r02_lora_step_sq_counters.csv > gpurun_out/pf/sq_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/fetch.log 2>&1

@@ -1,6 +1,6 @@
 """Turn rocprofv3 outputs of `bench.py` into the tables committed under profiles/.
 
-  python tools/profile_tables.py stats  <kernel-trace dir> <steps incl. warmup> <out prefix>     # per-kernel table + roofline column
+  python tools/profile_tables.py stats  <kernel-trace dir> <steps incl. warmup> <out prefix> [note]     # per-kernel table + roofline column
   python tools/profile_tables.py sq     <pmc dir> <out csv>                                      # SQ counters per kernel
   python tools/profile_tables.py traffic <fetch dir> <write dir> <out csv>                       # gate/up GEMM call: main + split-K tail + reduce
 
@@ -29,13 +29,13 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:64]
 
 
-def stats(d, steps, prefix):
+def stats(d, steps, prefix, note=""):
     f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
     rs = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rs)
     with open(f"profiles/{prefix}_kernel_table.csv", "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps {steps - 2} --warmup 2 --no-cpu-baseline` ({steps} steps in the trace, model init included); "
-                "achieved = algorithmic work per call (tools/profile_tables.py WORK) / avg duration; frac = achieved / (8 TB/s | 2.5 PFLOP/s)\n")
+                "achieved = algorithmic work per call (tools/profile_tables.py WORK) / avg duration; frac = achieved / (8 TB/s | 2.5 PFLOP/s)" + (f"; {note}" if note else "") + "\n")
         o.write("kernel,calls_per_step,avg_us,ms_per_step,pct_of_kernel_time,bound,achieved,unit,frac_of_peak\n")
         for r in rs:
             t = float(r["TotalDurationNs"])
@@ -70,7 +70,7 @@ def stats(d, steps, prefix):
         elif "norm" in n: groups["norms"] += t
         else: groups["other"] += t
     with open(f"profiles/{prefix}_kernel_groups.txt", "w") as o:
-        o.write(f"kernel time {tot / 1e6 / steps:.1f} ms/step over {steps} traced steps (incl. 2 warm-up steps and model init)\n")
+        o.write(f"kernel time {tot / 1e6 / steps:.1f} ms/step over {steps} traced steps (incl. 2 warm-up steps and model init)" + (f"; {note}" if note else "") + "\n")
         for k, v in groups.items():
             o.write(f"  {k:16s} {100 * v / tot:5.1f} %  {v / 1e6 / steps:6.1f} ms/step\n")
     print(open(f"profiles/{prefix}_kernel_groups.txt").read())
@@ -165,5 +165,5 @@ def traffic(dfetch, dwrite, out):
 
 
 if __name__ == "__main__":
-    {"stats": lambda: stats(sys.argv[2], int(sys.argv[3]), sys.argv[4]), "sq": lambda: sq(sys.argv[2], sys.argv[3]),
+    {"stats": lambda: stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else ""), "sq": lambda: sq(sys.argv[2], sys.argv[3]),
      "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4])}[sys.argv[1]]()
