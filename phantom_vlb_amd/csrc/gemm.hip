@@ -51,7 +51,8 @@ struct GemmArgs {
 // the SAME 8 W panels, so a W panel comes out of HBM once and A (48-77 MB here) is re-read from the Infinity Cache.
 // Against contiguous per-XCD runs over bands of 4 row tiles (order 0: 8 XCDs in 8 different places, 96 distinct panels
 // per round instead of ~40) the same kernel measured +2 % (LoRA batch) / +7 % (frozen batch) on gate/up, -1.5 % / -2.3 %
-// on the whole step (tools/ab_step_variant.py).  Orders 0-7 exist for A/B in the tools build.
+// on the whole step (tools/ab_step_variant.py).  Orders 0-7 exist for A/B in the tools build.  When A is the larger operand
+// and too large for the Infinity Cache the host picks order 2 instead (row bands dealt across the XCDs; pick_order).
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int pid, int sub, int BM, int BN, int& m0, int& n0) {
   int tm, tn;
   if (p.order & 4) {
@@ -985,7 +986,19 @@ VLB_TUNABLE int g_variant = 3;      // 0: lock-step double buffer, 1: ping-pong 
 VLB_TUNABLE int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tuning only)
 VLB_TUNABLE int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 VLB_TUNABLE int g_tile_order = 3;   // GemmArgs::order: bit 0 column bands of 8, bit 1 XCD chunks dealt per round, bit 2 16x16 rounds (A/B: variant bits 10-12 XOR 3)
+VLB_TUNABLE int g_order_auto = 1;   // pick_order's shape rule (A/B: variant bit 13 disables it)
 VLB_TUNABLE int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
+
+// Tile order for a shape.  The order decides which operand is swept once and which is re-read once per band, i.e. which
+// one has to come back out of the 256 MB Infinity Cache: order 3 (column bands: W once, A re-read per band) unless A is the
+// larger operand AND too large to stay cached (> 128 MB), then order 2 (row bands dealt across the XCDs: A once, W re-read).
+// Measured (tools/bench_gemm_variants.py): gate/up at M = 5861 / 9447 / 15630 prefers 3 (+2 / +7 / +4 % over order 0), at
+// M = 31260 (A = 256 MB) order 2 (+5 % over 3); `down` (K = 14336) at M >= 9447 (A >= 271 MB) order 2 (+2-4 %).
+inline int pick_order(int M, int N, int K) {
+  const double a_bytes = 2.0 * M * K, w_bytes = 2.0 * N * K;
+  const int o = (a_bytes > w_bytes && a_bytes > 128e6) ? 2 : 3;
+  return (g_tile_order == 3 && g_order_auto) ? o : g_tile_order;        // tools build: an explicit A/B order wins (variant bit 13: no shape rule)
+}
 
 // How the partial last wave of `tiles` tiles (nk K-tiles each) is run.  Costs are in units of one full wave of
 // tiles: whole tiles 1.0; re-cut 256x128 halves 0.62 (measured 0.6-0.8); split-K 1/s plus ~16 K-tiles' worth
@@ -1195,7 +1208,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
   a.M = M; a.N = N; a.K = K; a.K2 = K2;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = (bf16*)aux; a.ldaux = ldaux;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = pick_order(M, N, K); a.aux = (bf16*)aux; a.ldaux = ldaux;
   a.wide = ((uintptr_t)C % 16) == 0 && ldc % 8 == 0 && (!aux || (((uintptr_t)aux % 16) == 0 && ldaux % 8 == 0 && (N / 2) % 8 == 0));
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) && (!aux || (ldaux % 4 == 0 && (N / 2) % 4 == 0)) &&
@@ -1321,7 +1334,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   a.M = M; a.N = N; a.K = K; a.K2 = 64;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
-  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = g_tile_order; a.aux = nullptr; a.ldaux = 0;
+  a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = pick_order(M, N, K); a.aux = nullptr; a.ldaux = 0;
   a.wide = 1;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
@@ -1363,6 +1376,7 @@ extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_force_tile = force_tile;
   g_tail_split = (variant & 0x100) ? 0 : 1;    // bit 8 disables the tail split (A/B)
   g_tail_splitk = (variant & 0x200) ? 0 : 1;   // bit 9 disables the split-K tail (A/B)
+  g_order_auto = (variant & 0x2000) ? 0 : 1;
   g_tile_order = ((variant >> 10) & 7) ^ 3;       // variant word 3 = product default (order 3)
 }
 #endif

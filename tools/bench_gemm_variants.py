@@ -25,6 +25,9 @@ def main():
                   ("d_gu", 5861, 4096, 28672), ("d_down", 5861, 14336, 4096)]
     if os.environ.get("VLB_SHAPES") == "frozen":        # the frozen batch (M = 9447 packed rows)
         shapes = [("qkv", 9447, 6144, 4096), ("o", 9447, 4096, 4096), ("gate_up", 9447, 28672, 4096), ("down", 9447, 4096, 14336)]
+    if os.environ.get("VLB_SHAPES", "").startswith("rows="):   # VLB_SHAPES=rows=31200: the decoder projections at another row count
+        M = int(os.environ["VLB_SHAPES"][5:])
+        shapes = [("qkv", M, 6144, 4096), ("o", M, 4096, 4096), ("gate_up", M, 28672, 4096), ("down", M, 4096, 14336)]
     for name, M, N, K in shapes:
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
