@@ -179,15 +179,25 @@ __device__ __forceinline__ void store_swiglu8(const GemmArgs& p, const f32x4& g0
 }
 
 // bias / activation / residual of one fragment piece: lane holds C[m][n .. n+3]
+// ACT is a compile-time parameter: every fully unrolled epilogue nest then holds the code of ONE activation (see the
+// instruction-cache note at w4_store_frag2); bias and residual stay run-time tests (a load and an add each).
+template <int ACT>
+__device__ __forceinline__ float act_apply(float x) {
+  if constexpr (ACT == VLB_ACT_QUICK_GELU) return quick_gelu_f(x);
+  else if constexpr (ACT == VLB_ACT_GELU) return gelu_erf_f(x);
+  else if constexpr (ACT == VLB_ACT_SILU) return silu_f(x);
+  else return x;
+}
+template <int ACT>
 __device__ __forceinline__ bf16x4 w4_frag_value(const GemmArgs& p, f32x4 v, int m, int n) {
   if (p.bias) {
     const bf16x4 bb = *reinterpret_cast<const bf16x4*>(p.bias + n);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += (float)bb[e];
   }
-  if (p.act != VLB_ACT_NONE) {
+  if constexpr (ACT != VLB_ACT_NONE) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    for (int e = 0; e < 4; ++e) v[e] = act_apply<ACT>(v[e]);
   }
   if (p.residual) {
     const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
@@ -199,6 +209,14 @@ __device__ __forceinline__ bf16x4 w4_frag_value(const GemmArgs& p, f32x4 v, int 
   for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
   return o;
 }
+// run `BODY(ACT)` with the launch's activation as a compile-time constant (uniform dispatch, one nest executes)
+#define VLB_DISPATCH_ACT(act, BODY)                        \
+  do {                                                     \
+    if ((act) == VLB_ACT_QUICK_GELU) { BODY(VLB_ACT_QUICK_GELU) } \
+    else if ((act) == VLB_ACT_GELU) { BODY(VLB_ACT_GELU) }        \
+    else if ((act) == VLB_ACT_SILU) { BODY(VLB_ACT_SILU) }        \
+    else { BODY(VLB_ACT_NONE) }                                   \
+  } while (0)
 
 // LDS image of a [rows][64] bf16 tile: 128-byte rows, 16-byte chunk c of row r lives at slot
 // c ^ ((r>>1)&7).  Two rows share one 256-byte bank row, so the 16 rows x 1 chunk column that a
@@ -313,24 +331,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_kernel(GemmArgs p) {
   }
 
   // ---- epilogue: lane owns n = nbase + fq*4 + {0..3} of row m = mbase + fr, per 16x16 tile
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * TM + i * 16 + fr;
-    if (m >= p.M) continue;
-    if (p.wide) {             // C rows 16-byte aligned: adjacent fragments paired into 16-byte stores (store_pair16)
-#pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int n = n0 + wn * TN + j * 16 + fq * 4;
-        store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value(p, acc[i][j], m, n), w4_frag_value(p, acc[i][j + 1], m, n + 16), fq);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * TN + j * 16 + fq * 4;
-        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value(p, acc[i][j], m, n);
-      }
-    }
+  // C rows 16-byte aligned (p.wide): adjacent fragments paired into 16-byte stores (store_pair16); one nest per activation
+#define PP_EPILOGUE_WIDE(ACT)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+    const int m = m0 + wm * TM + i * 16 + fr;                                                                            \
+    if (m >= p.M) continue;                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; j += 2) {                                                                  \
+      const int n = n0 + wn * TN + j * 16 + fq * 4;                                                                      \
+      store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value<ACT>(p, acc[i][j], m, n), w4_frag_value<ACT>(p, acc[i][j + 1], m, n + 16), fq); \
+    }                                                                                                                    \
   }
+#define PP_EPILOGUE_NARROW(ACT)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+    const int m = m0 + wm * TM + i * 16 + fr;                                                                            \
+    if (m >= p.M) continue;                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                     \
+      const int n = n0 + wn * TN + j * 16 + fq * 4;                                                                      \
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value<ACT>(p, acc[i][j], m, n);                 \
+    }                                                                                                                    \
+  }
+  if (p.wide) VLB_DISPATCH_ACT(p.act, PP_EPILOGUE_WIDE);
+  else VLB_DISPATCH_ACT(p.act, PP_EPILOGUE_NARROW);
+#undef PP_EPILOGUE_WIDE
+#undef PP_EPILOGUE_NARROW
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,24 +524,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * TM + i * 16 + fr;
-    if (m >= p.M) continue;
-    if (p.wide) {             // C rows 16-byte aligned: adjacent fragments paired into 16-byte stores (store_pair16)
-#pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int n = n0 + wn * TN + j * 16 + fq * 4;
-        store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value(p, acc[i][j], m, n), w4_frag_value(p, acc[i][j + 1], m, n + 16), fq);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * TN + j * 16 + fq * 4;
-        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value(p, acc[i][j], m, n);
-      }
-    }
+  // C rows 16-byte aligned (p.wide): adjacent fragments paired into 16-byte stores (store_pair16); one nest per activation
+#define PP_EPILOGUE_WIDE(ACT)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+    const int m = m0 + wm * TM + i * 16 + fr;                                                                            \
+    if (m >= p.M) continue;                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; j += 2) {                                                                  \
+      const int n = n0 + wn * TN + j * 16 + fq * 4;                                                                      \
+      store_pair16(p.C + (int64_t)m * p.ldc, n, w4_frag_value<ACT>(p, acc[i][j], m, n), w4_frag_value<ACT>(p, acc[i][j + 1], m, n + 16), fq); \
+    }                                                                                                                    \
   }
+#define PP_EPILOGUE_NARROW(ACT)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                       \
+    const int m = m0 + wm * TM + i * 16 + fr;                                                                            \
+    if (m >= p.M) continue;                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                     \
+      const int n = n0 + wn * TN + j * 16 + fq * 4;                                                                      \
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = w4_frag_value<ACT>(p, acc[i][j], m, n);                 \
+    }                                                                                                                    \
+  }
+  if (p.wide) VLB_DISPATCH_ACT(p.act, PP_EPILOGUE_WIDE);
+  else VLB_DISPATCH_ACT(p.act, PP_EPILOGUE_NARROW);
+#undef PP_EPILOGUE_WIDE
+#undef PP_EPILOGUE_NARROW
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,7 +678,7 @@ __device__ __forceinline__ void w4_swiglu_bwd_value(const GemmArgs& p, const f32
 // kind's fully unrolled loop nest is a compact, contiguous instruction stream: with the kinds as run-time branches inside
 // every fragment the executed path hopped over ~280 KB of never-executed activation code per tile - instruction-cache
 // misses that cost the plain epilogue ~8 % of a whole K = 4096 GEMM (1.11 -> 1.03 ms on gate/up at the LoRA batch).
-enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_SWIGLU_BWD = 2, EPI_GENERIC = 3 };
+enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_SWIGLU_BWD = 2, EPI_GENERIC = 3 };     // EPI_GENERIC + act (0..3): bias / activation / residual
 __device__ __forceinline__ bf16x4 cvt4(const f32x4& v) {
   bf16x4 o;
 #pragma unroll
@@ -675,8 +703,9 @@ __device__ __forceinline__ void w4_store_frag2(const GemmArgs& p, const f32x4& v
 #pragma unroll
     for (int e = 0; e < 4; ++e) { xa[e] += (float)ra[e]; xb[e] += (float)rb[e]; }
     store_pair16(crow, n, cvt4(xa), cvt4(xb), fq);
-  } else {
-    store_pair16(crow, n, w4_frag_value(p, va, m, n), w4_frag_value(p, vb, m, n + 16), fq);
+  } else {       // EPI_GENERIC + ACT: KIND = EPI_GENERIC + the activation code
+    constexpr int ACT = KIND - EPI_GENERIC;
+    store_pair16(crow, n, w4_frag_value<ACT>(p, va, m, n), w4_frag_value<ACT>(p, vb, m, n + 16), fq);
   }
 }
 // which epilogue a launch needs (uniform): bias or an activation -> generic
@@ -942,7 +971,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   if (kind == EPI_PLAIN) { W4_EPILOGUE(EPI_PLAIN) return; }
   if (kind == EPI_RESIDUAL) { W4_EPILOGUE(EPI_RESIDUAL) return; }
   if (kind == EPI_SWIGLU_BWD) { W4_EPILOGUE(EPI_SWIGLU_BWD) return; }
-  W4_EPILOGUE(EPI_GENERIC)
+#define W4_EPILOGUE_ACT(ACT) W4_EPILOGUE(EPI_GENERIC + ACT)
+  VLB_DISPATCH_ACT(p.act, W4_EPILOGUE_ACT);
+#undef W4_EPILOGUE_ACT
 #undef W4_EPILOGUE
 }
 
@@ -977,7 +1008,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (kind == EPI_PLAIN) { W4_REDUCE_EPILOGUE(EPI_PLAIN) return; }
   if (kind == EPI_RESIDUAL) { W4_REDUCE_EPILOGUE(EPI_RESIDUAL) return; }
   if (kind == EPI_SWIGLU_BWD) { W4_REDUCE_EPILOGUE(EPI_SWIGLU_BWD) return; }
-  W4_REDUCE_EPILOGUE(EPI_GENERIC)
+#define W4_REDUCE_EPILOGUE_ACT(ACT) W4_REDUCE_EPILOGUE(EPI_GENERIC + ACT)
+  VLB_DISPATCH_ACT(p.act, W4_REDUCE_EPILOGUE_ACT);
+#undef W4_REDUCE_EPILOGUE_ACT
 #undef W4_REDUCE_EPILOGUE
 }
 
