@@ -78,3 +78,20 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_f(1.702f * x); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// 16-byte epilogue stores.  In the accumulator layout a lane (fr, fq) owns columns 4fq..4fq+3 of a 16-column fragment,
+// i.e. 8 bytes of bf16: the four lanes of a row would each store 8 bytes per fragment.  For two ADJACENT fragments j, j+1
+// (a = this lane's piece of j, b = of j+1) one v_permlane16_swap per dword hands the odd-fq lanes' pieces of j to their
+// even neighbours and the even lanes' pieces of j+1 to the odd ones: an even lane then holds columns 4fq..4fq+7 of
+// fragment j, an odd lane columns 4(fq-1)..4(fq-1)+7 of fragment j+1 - one 16-byte store each instead of two 8-byte
+// ones (half the store instructions of the serial tile tail, 64 contiguous bytes per row per instruction).
+// row = &C[m][0], n = the column of this lane's piece of fragment j (16-byte aligned for even fq).
+__device__ __forceinline__ void store_pair16(bf16* row, int n, bf16x4 a, bf16x4 b, int fq) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+  const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+  *reinterpret_cast<u32x4*>(row + n + ((fq & 1) ? 12 : 0)) = o;
+}

@@ -181,6 +181,33 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
   for (; kt < nk; ++kt) tile(kt, std::false_type{});
 #undef VLB_VMCNT
   // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}
+  // (C rows 16-byte aligned: adjacent fragments paired into 16-byte stores, store_pair16 in common.hpp; else 8-byte pieces)
+  auto value = [&](const f32x4& a, int m, int n) {
+    f32x4 v = a;
+    if (p.residual) {
+      const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+    return o;
+  };
+  const bool wide = ((uintptr_t)p.C % 16) == 0 && p.ldc % 8 == 0;
+  if (wide) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
+        store_pair16(p.C + (int64_t)m * p.ldc, n, value(acc[j][i], m, n), value(acc[j + 1][i], m, n + 16), g);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wm * 128 + i * 16 + fr;
@@ -188,16 +215,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
-      f32x4 v = acc[j][i];
-      if (p.residual) {
-        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = value(acc[j][i], m, n);
     }
   }
 }
