@@ -74,8 +74,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// 1 / (1 + e^-x) through v_rcp_f32 (1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup, ~10 instructions):
+// these run once per output element in the GEMM epilogues (SwiGLU forward / backward, quick-GELU), where with one wave per
+// SIMD every VALU instruction is on the tile's serial tail; the result is rounded to bf16 right after.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * sigmoid_f(1.702f * x); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
