@@ -19,5 +19,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 VLB_ROWS=9447 VLB_CLIPS=5 python3 tools/profile_tables.py stats gpurun_out/pf/frozen 10 r02_bench_frozen7b > gpurun_out/pf/frozen_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/full8 -- python3 bench.py --workload full --fp8 --steps 4 --warmup 2 > gpurun_out/pf/full8.log 2>&1
 python3 tools/profile_tables.py stats gpurun_out/pf/full8 6 r02_bench_full7b_fp8 > gpurun_out/pf/full8_tables.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/full -- python3 bench.py --workload full --steps 4 --warmup 2 > gpurun_out/pf/full.log 2>&1
+python3 tools/profile_tables.py stats gpurun_out/pf/full 6 r02_bench_full7b > gpurun_out/pf/full_tables.log 2>&1
 mkdir -p gpurun_out/pf/out && cp profiles/r02_* gpurun_out/pf/out/
 find gpurun_out/pf -name "*kernel_trace.csv" -delete; find gpurun_out/pf -name "*counter_collection.csv" -delete; find gpurun_out/pf -name "*.db" -delete
