@@ -26,11 +26,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
-# L2->fabric bytes of ONE gate/up GEMM call, measured offline with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE
-# passes, gfx950 2x read correction; tools/profile_tables.py traffic).  Only valid for that shape.
-GATEUP_TRAFFIC_BYTES = {(5861, 28672, 4096): 3.150e9,     # default (LoRA, packed rows; GEMM + SwiGLU + saved pre-activations), main launch + split-K tail + reduce: profiles/r02_gemm_gateup_hbm_traffic_lora.csv
-                        (9447, 28672, 4096): 3.746e9,     # --workload frozen, packed rows, main launch: profiles/r01_gemm_gateup_hbm_traffic_frozen_w4.csv
-                        (10240, 28672, 4096): 3.904e9}    # frozen --no-pack, earlier ping-pong kernel: profiles/r01_gemm_gateup_hbm_traffic.csv
+
+
+def gateup_traffic(shape):
+    """L2->fabric bytes of ONE gate/up GEMM call of this (M, N, K), as measured with rocprofv3 --pmc (separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 2x read correction) and recorded by `tools/profile_tables.py traffic` in the tracked file
+    profiles/gateup_traffic.json - the line and profiles/ cannot disagree.  (bytes, source file) or (None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gateup_traffic.json")) as f:
+            e = json.load(f).get("%d,%d,%d" % tuple(shape))
+        return (float(e["bytes"]), e["source"]) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 # SURVEY.md 8(d): algorithmic TFLOP per clip
 TFLOP_PER_CLIP = {"frozen": 36.53, "lora": 67.8, "full": 100.8}
 
@@ -180,6 +189,10 @@ def main():
     from phantom_vlb_amd.synthetic import synthetic_batch
 
     lora, full = a.workload == "lora", a.workload == "full"
+    if full and a.shard_frozen:
+        print("bench.py: --shard-frozen shards FROZEN decoder weights; with --workload full they train (their gradients and "
+              "optimiser state are sharded by the data-parallel step itself)", file=sys.stderr)
+        sys.exit(2)
     B = a.batch or (5 if a.workload == "frozen" else 3)
     num_target = a.num_target or (65536 if full else 2048)
     cfg = VLBLitModuleConfig(
@@ -237,17 +250,21 @@ def main():
     # ---- dominant-kernel timing: event pairs around every gate/up GEMM launch of the timed steps
     probe = ops.enable_gemm_probe(N=2 * g.ff, K=g.dim)
     barrier()
+    ops.profile_marker()                      # kernel traces are cut to [marker, marker] by tools/profile_tables.py
+    barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    ops.profile_marker()
     ops.disable_gemm_probe()
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches, (pM, pN, pK) = probe.result()
+    traffic, traffic_src = gateup_traffic((pM, pN, pK))
     if rank == 0:
         clips = world * B * a.steps
         value = clips / dt
@@ -284,8 +301,9 @@ def main():
                          + ("vlb_gemm_swiglu_save call (epilogue: + LoRA pair, SwiGLU, saved pre-activations; FLOPs counted: the base GEMM only)" if lora
                             else "vlb_gemm_bf16 call"), "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": GATEUP_TRAFFIC_BYTES.get((pM, pN, pK)),
-                         "traffic_note": "L2->fabric bytes per call from rocprofv3 PMC passes (profiles/r02_gemm_gateup_hbm_traffic_lora.csv; frozen shapes: r01_*); "
+                         "traffic": traffic,
+                         "traffic_note": (f"L2->fabric bytes per call from rocprofv3 PMC passes ({traffic_src}, via profiles/gateup_traffic.json); "
+                                          if traffic is not None else "no PMC collection on record for this shape (profiles/gateup_traffic.json); ")
                          + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN + 1.0 * pM * pN:.3e} (A | t, W | B, saved [gate|up] [M,N] and silu(gate)*up [M,N/2], bf16)" if lora else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
@@ -296,24 +314,34 @@ def main():
     else:
         out = None
 
+    import threading
+    emit_lock, emitted = threading.Lock(), []
+
     def emit(variant):
-        if rank == 0:
-            out["config"]["sharded_frozen_variant"] = variant
-            print(json.dumps(out), flush=True)
+        """Exactly one JSON line, whoever gets here first (the main thread or the watchdog)."""
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(True)
+            if rank == 0:
+                out["config"]["sharded_frozen_variant"] = variant
+                print(json.dumps(out), flush=True)
 
     # ---- N > 1: the fsdp.yaml-equivalent layout of the frozen decoder next to the replicated default (SURVEY.md 8e asks
     # for both): after the headline measurement, keep 1/N of every frozen layer per rank and time a few steps more.  The
-    # headline number above is already final; a watchdog on every rank makes sure it is printed even if the extra
-    # variant's collectives stall (rank 0 prints the line with the variant marked as timed out, every rank exits 0).
+    # headline number above is already final; should the extra variant's collectives stall, a watchdog on every rank prints
+    # the line with the stall recorded in it, says so on stderr and exits NON-ZERO (3): a hang is never reported as success.
     shard_variant = None
     if world > 1 and not a.shard_frozen and not full and os.environ.get("VLB_BENCH_SHARD_VARIANT", "1") == "1":
-        import threading
+        limit_s = float(os.environ.get("VLB_BENCH_SHARD_VARIANT_LIMIT_S", "120"))
 
         def bail():
-            emit({"error": "sharded-frozen variant did not finish within its time limit; headline unaffected"})
-            sys.stdout.flush()
-            os._exit(0)
-        dog = threading.Timer(float(os.environ.get("VLB_BENCH_SHARD_VARIANT_LIMIT_S", "120")), bail)
+            emit({"error": f"STALL: the sharded-frozen variant did not finish within {limit_s:.0f} s (collectives hung?); "
+                           "headline value measured before it and unaffected; process exits with status 3"})
+            print(f"bench.py[rank {rank}]: sharded-frozen variant stalled for {limit_s:.0f} s - exiting with status 3",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        dog = threading.Timer(limit_s, bail)
         dog.daemon = True
         dog.start()
         try:

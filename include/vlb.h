@@ -394,8 +394,29 @@ int vlb_allgather_direct(void* comm, const void* shard, void* full, int64_t shar
  * vlb_reducescatter_stage_floats(n_per_rank, world) floats; n_per_rank % 4 == 0, 16-byte aligned buffers. */
 int64_t vlb_reducescatter_stage_floats(int64_t n_per_rank, int world);
 int vlb_reducescatter_direct(void* comm, const float* send, float* out, int64_t n_per_rank, float* stage, void* stream);
+/* The same exchange for bf16 buffers (the bf16 gradients of the full fine-tune's backbone store, configs[4]): slices
+ * travel as bf16, are widened to fp32, summed in rank order and rounded to bf16 ONCE.  `stage` holds
+ * n_per_rank * world bf16 elements; n_per_rank % 8 == 0, 16-byte aligned buffers. */
+int vlb_reducescatter_direct_bf16(void* comm, const void* send, void* out, int64_t n_per_rank, void* stage, void* stream);
+/* The local half of both reduce-scatters on its own: out[i] = sum over r = 0..world-1, IN THAT ORDER, of
+ * stage[r*n_per_rank + i] (is_bf16 = 0: fp32 in / out; 1: bf16 in, fp32 accumulate, bf16 out).  No communicator: the
+ * fixed-order reduction can be verified for any world size on one GPU with hand-staged slices. */
+int vlb_reduce_slices(const void* stage, void* out, int64_t n_per_rank, int world, int is_bf16, void* stream);
 /* values[0..count) summed over ranks in place (the clip norm's sum of squares, logged losses) */
 int vlb_allreduce_scalar(void* comm, float* values, int count, void* stream);
+
+/* The reference's two exported head layers on their own (src/__init__.py:3-13; on the training path they run fused inside
+ * vlb_head_fwd / vlb_head_bwd):
+ *   HRFConvolveLayer.forward (src/utils.py:44-56)   out[B,E] = einsum('bse,bs->be', embeddings[B,S,E], weights[B,S])
+ *     embeddings bf16 (emb_is_f32 = 0, out bf16) or fp32 (1, out fp32); weights fp32; fp32 accumulation in a fixed order;
+ *     ws: vlb_hrf_pool_ws_floats(B, E) floats.
+ *   RidgeRegressionLayer.forward (src/utils.py:59-73)   pred[B,V] = x[B,E] . W[V,E]^T + b  (fp32 out), *l2_out = lambda * ||W||_F^2
+ *     x, W, b bf16; ws: vlb_ridge_ws_floats(V) floats. */
+int64_t vlb_hrf_pool_ws_floats(int B, int E);
+int vlb_hrf_pool(const void* embeddings, int emb_is_f32, const float* weights, void* out, float* ws, int B, int S, int E, void* stream);
+int64_t vlb_ridge_ws_floats(int V);
+int vlb_ridge_fwd(const void* x, const void* ridge_w, const void* ridge_b, float* pred, float* l2_out, float* ws, int B, int E, int V,
+                  float l2_lambda, void* stream);
 
 /* head dropout mask (litmodule :226,251 nn.Dropout(p) in training): out[i] = keep_i / (1-p), keep_i from a
  * counter-based hash of (seed, i) with 16 random bits per element (same mixer as the LoRA masks).  The result is
@@ -403,6 +424,9 @@ int vlb_allreduce_scalar(void* comm, float* values, int count, void* stream);
 int vlb_dropout_keep_scale(float* out, int64_t n, float p, uint32_t seed, void* stream);
 
 /* misc */
+/* One empty single-wave launch named `vlb_profile_marker_kernel`: bench.py brackets its timed region with two of them so
+ * that tools/profile_tables.py can cut model construction and warm-up steps out of a rocprofv3 kernel trace. */
+int vlb_profile_marker(void* stream);
 int vlb_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 

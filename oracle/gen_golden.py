@@ -58,9 +58,14 @@ def pin_head():
     B, S, E, V = 4, 64, 32, 128
     emb, w = torch.randn(B, S, E), torch.rand(B, S)
     pooled_ref = ref.HRFConvolveLayer()(emb, w)
-    pooled = torch.einsum("bse,bs->be", emb, w)
+    pooled = O.hrf_convolve(emb, w)
     assert torch.equal(pooled_ref, pooled)
     ridge = ref.RidgeRegressionLayer(E, V, l2_lambda=1e-3)
+    xr = torch.randn(B, E)                 # the two exported layers on their own (src/__init__.py:3-13), as the oracle restates them
+    o_ref, l_ref = ridge(xr)
+    o_mine, l_mine = O.ridge_regression(ridge.linear.weight.detach(), ridge.linear.bias.detach(), xr, 1e-3)
+    assert torch.allclose(o_mine, o_ref, atol=1e-6) and torch.allclose(l_mine, l_ref, rtol=1e-6)
+    assert torch.equal(O.ridge_regression(ridge.linear.weight.detach(), ridge.linear.bias.detach(), xr, 1e-3, False), ridge(xr, False))
     g = O.Geometry(dim=E, num_target=V, l2_lambda=1e-3)
     p = {"layer_norm1.weight": torch.ones(E), "layer_norm1.bias": torch.zeros(E),
          "layer_norm2.weight": torch.ones(E), "layer_norm2.bias": torch.zeros(E),

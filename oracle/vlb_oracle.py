@@ -478,15 +478,25 @@ def mistral_decoder(p, x, key_mask, g: Geometry, return_layers=False, lora_drop=
 # --------------------------------------------------------------------------------------
 # a9-a13: brain head + loss
 # --------------------------------------------------------------------------------------
+def hrf_convolve(embeddings, hrf_weights):
+    """HRFConvolveLayer.forward (src/utils.py:44-56): HRF-weighted sum of the token embeddings."""
+    return torch.einsum("bse,bs->be", embeddings, hrf_weights)
+
+
+def ridge_regression(weight, bias, x, l2_lambda, add_regularization=True):
+    """RidgeRegressionLayer.forward (src/utils.py:59-73): Linear(x) and l2_lambda * ||W||_F^2 (bias not penalised)."""
+    out = F.linear(x, weight, bias)
+    return (out, l2_lambda * weight.pow(2).sum()) if add_regularization else out
+
+
 def brain_head(p, hidden, weight_mask, g: Geometry, keep_mask=None, dropout_p=0.0):
     """LN1 -> einsum('bse,bs->be') -> LN2 -> dropout -> Linear ; l2 = lambda*||W||_F^2."""
     h = F.layer_norm(hidden, (g.dim,), p["layer_norm1.weight"], p["layer_norm1.bias"], g.ln_eps)
-    pooled = torch.einsum("bse,bs->be", h, weight_mask)
+    pooled = hrf_convolve(h, weight_mask)
     z = F.layer_norm(pooled, (g.dim,), p["layer_norm2.weight"], p["layer_norm2.bias"], g.ln_eps)
     if keep_mask is not None:
         z = z * keep_mask / (1.0 - dropout_p)
-    pred = F.linear(z, p["ridge_layer.linear.weight"], p["ridge_layer.linear.bias"])
-    l2 = g.l2_lambda * p["ridge_layer.linear.weight"].pow(2).sum()
+    pred, l2 = ridge_regression(p["ridge_layer.linear.weight"], p["ridge_layer.linear.bias"], z, g.l2_lambda)
     return pred, l2, dict(ln1=h, pooled=pooled, ln2=z)
 
 

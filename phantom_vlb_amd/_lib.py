@@ -99,11 +99,18 @@ SIGNATURES = {
     "vlb_allgather_direct": [P, P, P, L, P],
     "vlb_reducescatter_stage_floats": [L, I],
     "vlb_reducescatter_direct": [P, P, P, L, P, P],
+    "vlb_reducescatter_direct_bf16": [P, P, P, L, P, P],
+    "vlb_reduce_slices": [P, P, L, I, I, P],
+    "vlb_profile_marker": [P],
+    "vlb_hrf_pool_ws_floats": [I, I],
+    "vlb_hrf_pool": [P, I, P, P, P, I, I, I, P],
+    "vlb_ridge_ws_floats": [I],
+    "vlb_ridge_fwd": [P, P, P, P, P, P, I, I, I, F, P],
     "vlb_allreduce_scalar": [P, P, I, P],
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
-_RESTYPES = {"vlb_last_error": c_char_p, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
+_RESTYPES = {"vlb_last_error": c_char_p, "vlb_hrf_pool_ws_floats": c_int64, "vlb_ridge_ws_floats": c_int64, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
              "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64,
              "vlb_norm_bwd_ws_floats": c_int64, "vlb_rmsnorm_bwd_full_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
 

@@ -320,17 +320,21 @@ class Backbone:
         return ops.RowLayout(B, S, lens.tolist(), device=self.w.dev)
 
     # ---------------- fsdp.yaml-equivalent sharding of the frozen decoder weights (opt-in)
-    def enable_sharding(self, group=None):
+    def enable_sharding(self, group=None, comm=None):
         """Keep only this rank's 1/world shard of every decoder layer; full layers are all-gathered one
-        layer ahead of compute on a side stream (parallel.ShardedLayerStore)."""
+        layer ahead of compute on a side stream (parallel.ShardedLayerStore).  Frozen weights only: the full
+        fine-tune's decoder weights are optimiser state (parallel.ShardedFlatState shards their gradients and moments)."""
         from .parallel import ShardedLayerStore
+        if getattr(self, "trainable_decoder", False):
+            raise ValueError("enable_sharding(): the decoder weights train in this configuration (full fine-tune); "
+                             "only frozen decoder weights can be sharded per layer")
         side = torch.cuda.Stream(device=self.w.dev)
         keys = tuple(k for k in ("wqkv", "wo", "wgu", "wgu_il", "wdown") if k in self.w.layers[0])
-        self.store = ShardedLayerStore(self.w.layers, keys, group, stream=side)
+        self.store = ShardedLayerStore(self.w.layers, keys, group, stream=side, comm=comm)
         self.store_t = None
         if "wqkv_t" in self.w.layers[0]:
             tkeys = ("wqkv_t", "wo_t", "wgu_t", "wdown_t")
-            self.store_t = ShardedLayerStore(self.w.layers, tkeys, group, stream=side)
+            self.store_t = ShardedLayerStore(self.w.layers, tkeys, group, stream=side, comm=comm)
         for lw in self.w.layers:
             for k in list(lw):
                 if k in keys or k.endswith("_t"):
@@ -358,12 +362,14 @@ class Backbone:
     # The CLIP tower and the STC connector are frozen in the frozen-backbone and LoRA configurations (reference :86-99), so their
     # output for a batch depends on nothing the optimiser touches: the caller may start them for batch i+1 on a side stream
     # while step i's decoder runs (DevicePrefetcher does, bench.py does), and the step that consumes batch i+1 picks the result
-    # up instead of computing it in line.  Every step still computes the tower once for one batch - nothing is cached or reused;
-    # what changes is that ~14 % of the step (forward-only, one workgroup per CU kernels with their own tails) fills the holes
-    # of the decoder's launches: 211.7 -> 208.8 ms/step same-process on the 7B LoRA step.
-    @staticmethod
-    def _vision_key(vision_f32):
-        return (vision_f32.data_ptr(), tuple(vision_f32.shape), vision_f32._version)
+    # up instead of computing it in line.  Every step still computes the tower once for one batch - nothing is cached or reused.
+    #
+    # A staged batch is identified by the IDENTITY of its pixel tensor, never by its address: every queue entry holds a
+    # reference to the tensor it was computed from (which also pins the storage, so the caching allocator cannot hand the
+    # address to a later batch) and lookups compare with ``is`` plus the version counter (an in-place edit invalidates).
+    # Entries a consumer never asks for (rank-strided validation, limit_val_batches, a mid-epoch resume skip, max_steps) are
+    # dropped by discard_video_tokens(): DevicePrefetcher calls it for every batch it staged but did not hand over.
+    MAX_AHEAD = 4
 
     def _vision_compute(self, vision_f32, tower_only):
         g, B = self.g, vision_f32.shape[0]
@@ -376,7 +382,9 @@ class Backbone:
         (DevicePrefetcher's copy); without it the side stream waits for the current stream."""
         dev = self.w.dev
         if getattr(self, "_vis_stream", None) is None:
-            self._vis_stream, self._vis_queue = torch.cuda.Stream(device=dev), []
+            self._vis_stream = torch.cuda.Stream(device=dev)
+        if getattr(self, "_vis_queue", None) is None:
+            self._vis_queue = []
         st = self._vis_stream
         if ready_event is not None:
             st.wait_event(ready_event)
@@ -387,43 +395,57 @@ class Backbone:
             ev = torch.cuda.Event()
             ev.record(st)
         vision_f32.record_stream(st)
-        self._vis_queue.append(((self._vision_key(vision_f32), tower_only), vid, ev))
-        del self._vis_queue[:-4]                      # never more than a few batches ahead
+        self._vis_queue.append((vision_f32, vision_f32._version, tower_only, vid, ev))
+        del self._vis_queue[:-self.MAX_AHEAD]         # never more than a few batches ahead
 
     def defer_video_tokens(self, vision_f32, ready_event=None, tower_only=False):
         """Register a future batch; launch_deferred_video_tokens() (called by the step functions right behind their forward
         pass) enqueues it on the side stream."""
         if getattr(self, "_vis_pending", None) is None:
             self._vis_pending = []
-        self._vis_pending.append(((self._vision_key(vision_f32), tower_only), vision_f32, ready_event))
-        del self._vis_pending[:-4]
+        self._vis_pending.append((vision_f32, vision_f32._version, tower_only, ready_event))
+        del self._vis_pending[:-self.MAX_AHEAD]
 
     def launch_deferred_video_tokens(self):
         pend, self._vis_pending = getattr(self, "_vis_pending", None) or [], []
-        for key, vis, ev in pend:
-            if key[0] == self._vision_key(vis):       # still the tensor that was registered
-                self.prefetch_video_tokens(vis, ev, tower_only=key[1])
+        for vis, ver, tower_only, ev in pend:
+            if vis._version == ver:                   # still the pixels that were registered
+                self.prefetch_video_tokens(vis, ev, tower_only=tower_only)
+
+    def discard_video_tokens(self, vision_f32=None):
+        """Forget what was registered / computed ahead for this pixel tensor (``None``: for every batch): the batch will not be
+        consumed.  Nothing is synchronised; a result still being computed on the side stream is simply released."""
+        for name in ("_vis_queue", "_vis_pending"):
+            q = getattr(self, name, None)
+            if q:
+                q[:] = [e for e in q if vision_f32 is not None and e[0] is not vision_f32]
 
     def video_tokens(self, vision_f32, tower_only=False):
         """connector(vision_tower(pixels)) [B, Nv, dim] (``tower_only``: the tower's tokens) - computed here, or taken from
-        prefetch_video_tokens() when that ran for this very tensor (same storage, shape and version counter)."""
+        prefetch_video_tokens() when that ran for this very tensor object (and nobody wrote to it since).  A result that
+        was prefetched ``tower_only`` is completed with the connector in line when the consumer wants the tokens (full
+        fine-tune validation: the eval forward takes the frozen path)."""
         q = getattr(self, "_vis_queue", None)
-        key = (self._vision_key(vision_f32), tower_only)
+        cur = torch.cuda.current_stream(self.w.dev)
         if q:
-            for i, (k, vid, ev) in enumerate(q):
-                if k == key:
-                    del q[i]
-                    cur = torch.cuda.current_stream(self.w.dev)
-                    cur.wait_event(ev)
-                    vid.record_stream(cur)
-                    return vid
+            for i, (vis, ver, t_only, vid, ev) in enumerate(q):
+                if vis is not vision_f32:
+                    continue
+                del q[i]
+                if ver != vision_f32._version or (t_only is False and tower_only):
+                    break                             # stale pixels, or the tokens where the tower's features are wanted
+                cur.wait_event(ev)
+                vid.record_stream(cur)
+                if t_only and not tower_only:
+                    return self.connector(vid, vision_f32.shape[0])
+                return vid
         pend = getattr(self, "_vis_pending", None)
         if pend:                                      # registered but its own step came first: compute it here, once
-            for i, (k, vis, ev) in enumerate(pend):
-                if k == key:
+            for i, (vis, ver, t_only, ev) in enumerate(pend):
+                if vis is vision_f32:
                     del pend[i]
                     if ev is not None:
-                        torch.cuda.current_stream(self.w.dev).wait_event(ev)
+                        cur.wait_event(ev)
                     break
         return self._vision_compute(vision_f32, tower_only)
 

@@ -83,6 +83,55 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restr
   for (int r = 1; r < world; ++r) acc += *reinterpret_cast<const f32x4*>(stage + (int64_t)r * n + i * 4);
   *reinterpret_cast<f32x4*>(out + i * 4) = acc;
 }
+
+// bf16 form: 8 elements per lane; the `world` staged slices are widened to fp32, summed in rank order and rounded to
+// bf16 ONCE (the bf16 gradients of the full fine-tune's backbone store: what a bf16 ncclSum reduce-scatter would round
+// after every hop is rounded here a single time).
+__global__ __launch_bounds__(256) void reduce_slices_bf16_kernel(const bf16* __restrict__ stage, bf16* __restrict__ out, int64_t n8,
+                                                                 int64_t n, int world) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float acc[8];
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + i * 8);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (float)v[j];
+  for (int r = 1; r < world; ++r) {
+    v = *reinterpret_cast<const bf16x8*>(stage + (int64_t)r * n + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16)acc[j];
+  *reinterpret_cast<bf16x8*>(out + i * 8) = v;
+}
+
+int launch_reduce_slices(const void* stage, void* out, int64_t n, int world, int is_bf16, hipStream_t st) {
+  const int64_t per = is_bf16 ? 8 : 4, nv = n / per;
+  const dim3 grid((unsigned)((nv + 255) / 256));
+  if (is_bf16)
+    hipLaunchKernelGGL(reduce_slices_bf16_kernel, grid, dim3(256), 0, st, static_cast<const bf16*>(stage), static_cast<bf16*>(out), nv, n, world);
+  else
+    hipLaunchKernelGGL(reduce_slices_kernel, grid, dim3(256), 0, st, static_cast<const float*>(stage), static_cast<float*>(out), nv, n, world);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+// the exchange of a direct reduce-scatter: slice r of `stage` <- rank r's slice `rank` of ITS `send` buffer
+int exchange_slices(VlbComm* c, const char* send, char* stage, int64_t slice_bytes, hipStream_t st) {
+  hipError_t e = hipMemcpyAsync(stage + (int64_t)c->rank * slice_bytes, send + (int64_t)c->rank * slice_bytes, (size_t)slice_bytes,
+                                hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { vlb_set_error("reducescatter_direct: local copy failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
+  if (c->world > 1) {
+    VLB_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
+    for (int p = 0; p < c->world; ++p) {
+      if (p == c->rank) continue;
+      VLB_NCCL(g_rccl.Send(send + (int64_t)p * slice_bytes, (size_t)slice_bytes, ncclUint8, p, c->comm, st), "ncclSend");
+      VLB_NCCL(g_rccl.Recv(stage + (int64_t)p * slice_bytes, (size_t)slice_bytes, ncclUint8, p, c->comm, st), "ncclRecv");
+    }
+    VLB_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+  }
+  return VLB_OK;
+}
 }  // namespace
 
 extern "C" int vlb_comm_unique_id(void* id128_host) {
@@ -141,28 +190,33 @@ extern "C" int vlb_allgather_direct(void* comm, const void* shard, void* full, i
 
 extern "C" int64_t vlb_reducescatter_stage_floats(int64_t n_per_rank, int world) { return n_per_rank * (int64_t)world; }
 
+extern "C" int vlb_reduce_slices(const void* stage, void* out, int64_t n_per_rank, int world, int is_bf16, void* stream) {
+  const int per = is_bf16 ? 8 : 4;
+  VLB_REQUIRE(stage && out && n_per_rank > 0 && world >= 1 && n_per_rank % per == 0,
+              "reduce_slices: bad arguments (n_per_rank must be a multiple of %d)", per);
+  VLB_REQUIRE((((uintptr_t)stage | (uintptr_t)out) % 16) == 0 && ((n_per_rank * (is_bf16 ? 2 : 4)) % 16) == 0,
+              "reduce_slices: buffers and slices must be 16-byte aligned");
+  return launch_reduce_slices(stage, out, n_per_rank, world, is_bf16, as_stream(stream));
+}
+
 extern "C" int vlb_reducescatter_direct(void* comm, const float* send, float* out, int64_t n_per_rank, float* stage, void* stream) {
   VLB_REQUIRE(comm && send && out && stage && n_per_rank > 0 && n_per_rank % 4 == 0, "reducescatter_direct: bad arguments (n_per_rank must be a multiple of 4)");
   VLB_REQUIRE((((uintptr_t)send | (uintptr_t)out | (uintptr_t)stage) % 16) == 0, "reducescatter_direct: buffers must be 16-byte aligned");
   VlbComm* c = static_cast<VlbComm*>(comm);
   hipStream_t st = as_stream(stream);
-  const int64_t n = n_per_rank;
-  // slice r of the staging area <- rank r's slice `rank` of ITS buffer (own slice: local copy)
-  hipError_t e = hipMemcpyAsync(stage + (int64_t)c->rank * n, send + (int64_t)c->rank * n, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) { vlb_set_error("reducescatter_direct: local copy failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
-  if (c->world > 1) {
-    VLB_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
-    for (int p = 0; p < c->world; ++p) {
-      if (p == c->rank) continue;
-      VLB_NCCL(g_rccl.Send(send + (int64_t)p * n, (size_t)n, ncclFloat32, p, c->comm, st), "ncclSend");
-      VLB_NCCL(g_rccl.Recv(stage + (int64_t)p * n, (size_t)n, ncclFloat32, p, c->comm, st), "ncclRecv");
-    }
-    VLB_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
-  }
-  const int64_t n4 = n / 4;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, stage, out, n4, n, c->world);
-  VLB_LAUNCH_CHECK();
-  return VLB_OK;
+  int rc = exchange_slices(c, reinterpret_cast<const char*>(send), reinterpret_cast<char*>(stage), n_per_rank * (int64_t)sizeof(float), st);
+  if (rc != VLB_OK) return rc;
+  return launch_reduce_slices(stage, out, n_per_rank, c->world, 0, st);
+}
+
+extern "C" int vlb_reducescatter_direct_bf16(void* comm, const void* send, void* out, int64_t n_per_rank, void* stage, void* stream) {
+  VLB_REQUIRE(comm && send && out && stage && n_per_rank > 0 && n_per_rank % 8 == 0, "reducescatter_direct_bf16: bad arguments (n_per_rank must be a multiple of 8)");
+  VLB_REQUIRE((((uintptr_t)send | (uintptr_t)out | (uintptr_t)stage) % 16) == 0, "reducescatter_direct_bf16: buffers must be 16-byte aligned");
+  VlbComm* c = static_cast<VlbComm*>(comm);
+  hipStream_t st = as_stream(stream);
+  int rc = exchange_slices(c, static_cast<const char*>(send), static_cast<char*>(stage), n_per_rank * 2, st);
+  if (rc != VLB_OK) return rc;
+  return launch_reduce_slices(stage, out, n_per_rank, c->world, 1, st);
 }
 
 extern "C" int vlb_allreduce_scalar(void* comm, float* values, int count, void* stream) {

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void ridge_fwd_kernel(const bf16* __restrict__
           const float pv = wave_sum(acc[i]) + (float)bias[v];
           if (lane == 0) {
             pred[(int64_t)(b0 + i) * V + v] = pv;
-            const float d = pv - y[(int64_t)(b0 + i) * V + v];
+            const float d = y ? pv - y[(int64_t)(b0 + i) * V + v] : 0.f;
             mse += d * d;
           }
         }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void ridge_fwd_mfma_kernel(const bf16* __restr
         if (vv < V) {
           const float pv = acc[e] + red[0][e][lane] + red[1][e][lane] + red[2][e][lane] + (float)bias[vv];
           pred[(int64_t)fr * V + vv] = pv;
-          const float d = pv - y[(int64_t)fr * V + vv];
+          const float d = y ? pv - y[(int64_t)fr * V + vv] : 0.f;
           mse += d * d;
         }
       }
@@ -544,6 +544,60 @@ __global__ __launch_bounds__(256) void head_dhidden_kernel(const bf16* __restric
   }
 }
 
+// ---------------------------------------------------------------- standalone HRFConvolveLayer (src/utils.py:44-56)
+// out[b,e] = sum_s w[b,s] * x[b,s,e]: one pass over x, HBM-bound.  grid (HRF_SPLITS, ceil(E/512), B), 4 waves per block; a wave
+// walks every 4th token of its split (tokens with zero weight are skipped), a lane owns 8 columns; the four waves are summed
+// through LDS and the splits through fp32 slabs in a fixed order (reproducible).  T = bf16 or float embeddings.
+constexpr int HRF_SPLITS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void hrf_pool_kernel(const T* __restrict__ x, const float* __restrict__ w, float* __restrict__ slab,
+                                                       int S, int E) {
+  __shared__ float red[3][512];
+  const int b = blockIdx.z, c = blockIdx.y * 512 + (threadIdx.x & 63) * 8, wave = threadIdx.x >> 6;
+  const int per = (S + HRF_SPLITS - 1) / HRF_SPLITS, s0 = blockIdx.x * per, s1 = min(S, s0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < E) {
+    for (int s = s0 + wave; s < s1; s += 4) {
+      const float ws_ = w[(int64_t)b * S + s];
+      if (ws_ == 0.f) continue;
+      const T* xr = x + ((int64_t)b * S + s) * E + c;
+      float v[8];
+      if constexpr (sizeof(T) == 2) {
+        ld8(reinterpret_cast<const bf16*>(xr), v);
+      } else {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ws_ * v[j];
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave - 1][(threadIdx.x & 63) * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && c < E) {
+    float* dst = slab + ((int64_t)b * HRF_SPLITS + blockIdx.x) * E + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = (threadIdx.x & 63) * 8 + j;
+      dst[j] = ((acc[j] + red[0][k]) + red[1][k]) + red[2][k];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hrf_pool_reduce_kernel(const float* __restrict__ slab, T* __restrict__ out, int E) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  float a = 0.f;
+  for (int k = 0; k < HRF_SPLITS; ++k) a += slab[((int64_t)b * HRF_SPLITS + k) * E + e];
+  out[(int64_t)b * E + e] = (T)a;
+}
+
 int reserve_ridge_lds(int bytes) {
   static int reserved = 0;
   if (bytes > reserved) {
@@ -686,5 +740,46 @@ extern "C" int vlb_head_bwd(const void* hidden, const float* wmask, const void* 
                        wmask, stats, dpooled_ws, (bf16*)dhidden, S, E, rows, B, cu_rows);
     VLB_LAUNCH_CHECK();
   }
+  return VLB_OK;
+}
+
+// ---------------------------------------------------------------- the exported layers on their own
+extern "C" int64_t vlb_hrf_pool_ws_floats(int B, int E) { return (int64_t)B * HRF_SPLITS * E; }
+
+extern "C" int vlb_hrf_pool(const void* embeddings, int emb_is_f32, const float* weights, void* out, float* ws, int B, int S, int E,
+                            void* stream) {
+  VLB_REQUIRE(embeddings && weights && out && ws && B > 0 && S > 0 && E > 0 && E % 8 == 0, "hrf_pool: bad arguments (E must be a multiple of 8)");
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(HRF_SPLITS, (E + 511) / 512, B), rgrid((E + 255) / 256, B);
+  if (emb_is_f32) {
+    hipLaunchKernelGGL(hrf_pool_kernel<float>, grid, dim3(256), 0, st, (const float*)embeddings, weights, ws, S, E);
+    VLB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hrf_pool_reduce_kernel<float>, rgrid, dim3(256), 0, st, ws, (float*)out, E);
+  } else {
+    hipLaunchKernelGGL(hrf_pool_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)embeddings, weights, ws, S, E);
+    VLB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hrf_pool_reduce_kernel<bf16>, rgrid, dim3(256), 0, st, ws, (bf16*)out, E);
+  }
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int64_t vlb_ridge_ws_floats(int V) { return 2 * (int64_t)((V + RIDGE_ROWS - 1) / RIDGE_ROWS) + 8; }
+
+extern "C" int vlb_ridge_fwd(const void* x, const void* ridge_w, const void* ridge_b, float* pred, float* l2_out, float* ws, int B, int E,
+                             int V, float l2_lambda, void* stream) {
+  VLB_REQUIRE(x && ridge_w && ridge_b && pred && l2_out && ws && B > 0 && V > 0 && E > 0 && E % 8 == 0, "ridge_fwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  const int rblk = (V + RIDGE_ROWS - 1) / RIDGE_ROWS;
+  const int zlds = (B < BMAX ? B : BMAX) * E * 2;
+  if (int rc = reserve_ridge_lds(zlds)) return rc;
+  float* terms = ws + 2 * (int64_t)rblk;
+  hipLaunchKernelGGL(ridge_fwd_kernel, dim3(rblk), dim3(256), zlds, st, (const bf16*)ridge_w, (const bf16*)ridge_b, (const bf16*)x,
+                     (const float*)nullptr, pred, ws, B, E, V);
+  VLB_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, ws, rblk, 1.f / ((float)B * (float)V), l2_lambda, terms);
+  VLB_LAUNCH_CHECK();
+  hipError_t e = hipMemcpyAsync(l2_out, terms + 1, sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { vlb_set_error("ridge_fwd: copy failed: %s", hipGetErrorString(e)); return VLB_ERR_LAUNCH; }
   return VLB_OK;
 }

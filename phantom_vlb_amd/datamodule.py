@@ -191,11 +191,13 @@ class DevicePrefetcher:
     uploaded by the step itself).  Device tensors are tied to the consumer stream with ``record_stream`` so
     the caching allocator cannot recycle them while a kernel still reads them."""
 
-    def __init__(self, loader, device, keep_on_host=("language", "padvals"), on_staged=None):
+    def __init__(self, loader, device, keep_on_host=("language", "padvals"), on_staged=None, on_discard=None):
         """``on_staged(batch, event)``: called for every batch right after its copies were enqueued (event = copies done),
-        i.e. one step before the batch is handed over - VLBLitModule.prefetch_vision hooks in here."""
+        i.e. one step before the batch is handed over - VLBLitModule.prefetch_vision hooks in here.
+        ``on_discard(batch)``: called for a batch that was staged but will never be handed over (the consumer stopped
+        iterating: ``limit_val_batches``, ``max_steps``, an exception) - VLBLitModule.discard_prefetched_vision."""
         self.loader, self.device, self.keep = loader, torch.device(device), tuple(keep_on_host)
-        self.on_staged = on_staged
+        self.on_staged, self.on_discard = on_staged, on_discard
         self.sampler = getattr(loader, "sampler", None)
         self.stream = torch.cuda.Stream(device=self.device)
 
@@ -213,20 +215,40 @@ class DevicePrefetcher:
         return out, ev
 
     def __iter__(self):
-        it = iter(self.loader)
+        for _, batch in self.iter_selected():
+            yield batch
+
+    def iter_selected(self, select=None, limit=None):
+        """Yields ``(index in the underlying loader, batch)`` for the batches with ``select(index)`` true (all when None),
+        stopping in front of index ``limit``.  Only selected batches are copied to the device and announced through
+        ``on_staged``: a batch the consumer skips (another rank's validation batch, the part of an epoch a resumed run has
+        already seen) never starts a side-stream computation nobody would pick up."""
+        def wanted():
+            for i, b in enumerate(self.loader):
+                if limit is not None and i >= limit:
+                    return
+                if select is None or select(i):
+                    yield i, b
+        it = wanted()
+        nxt = None
         try:
-            nxt = self._stage(next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            cur, ev = nxt
-            try:
-                nxt = self._stage(next(it))          # batch i+1 starts moving before step i is enqueued
-            except StopIteration:
+            first = next(it, None)
+            if first is None:
+                return
+            nxt = (first[0],) + self._stage(first[1])
+            while nxt is not None:
+                idx, cur, ev = nxt
                 nxt = None
-            consumer = torch.cuda.current_stream(self.device)
-            consumer.wait_event(ev)
-            for v in cur.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(consumer)
-            yield cur
+                follow = next(it, None)               # batch i+1 starts moving before step i is enqueued
+                if follow is not None:
+                    nxt = (follow[0],) + self._stage(follow[1])
+                consumer = torch.cuda.current_stream(self.device)
+                consumer.wait_event(ev)
+                for v in cur.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(consumer)
+                yield idx, cur
+        finally:
+            if nxt is not None and self.on_discard is not None:      # staged, never handed over
+                self.on_discard(nxt[1])
+            it.close()

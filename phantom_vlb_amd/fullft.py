@@ -123,6 +123,7 @@ class FullFineTune:
         transposes) once per optimiser step, the decoder's weight gradients quantise their transposed operands along the
         token axis; attention, norms, the connector and the optimiser stay as they are."""
         self.g, self.bb, self.w, self.dev = g, backbone, backbone.w, device
+        backbone.trainable_decoder = True     # Backbone.enable_sharding refuses: these weights are optimiser state
         self.fp8 = bool(fp8_gemm)
         self.wq = {}                          # (layer, key) -> (uint8 e4m3 weights, uint8 scales)
         self.flat = FlatBackbone(g, self.w)

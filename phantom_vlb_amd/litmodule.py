@@ -291,6 +291,12 @@ class VLBLitModule(_Base):
         # dominant-kernel timing stays undisturbed).  A batch whose own step comes first is computed in line by that step.
         self.backbone.defer_video_tokens(batch["vision"], ready_event, tower_only=self.full is not None)
 
+    def discard_prefetched_vision(self, batch=None):
+        """A batch announced through prefetch_vision will not be consumed (``None``: none of the announced ones will)."""
+        vis = None if batch is None else batch.get("vision")
+        if batch is None or torch.is_tensor(vis):
+            self.backbone.discard_video_tokens(vis)
+
     def training_step(self, batch):
         """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
         self.train(True)

@@ -416,6 +416,11 @@ def dropout_keep_scale(B, E, p, seed, device):
     return out
 
 
+def profile_marker():
+    """An empty launch named vlb_profile_marker_kernel on the current stream (bench.py brackets its timed region)."""
+    check(lib.vlb_profile_marker(_stream()), "vlb_profile_marker")
+
+
 def cast_bf16(x_f32):
     out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
     check(lib.vlb_cast_f32_to_bf16(_dev(x_f32).data_ptr(), out.data_ptr(), x_f32.numel(), _stream()), "vlb_cast_f32_to_bf16")

@@ -6,18 +6,23 @@ multi-GPU mainline - only an unused Accelerate FSDP config (``fsdp.yaml``: FULL_
 TRANSFORMER_BASED_WRAP on the decoder layer, BACKWARD_PRE, forward prefetch) - so this module is
 the MI355X-native equivalent of that config, not a translation of torch FSDP:
 
-* ``FlatGradReducer``  - all trainable gradients live in ONE flat fp32 buffer, reduced by a single
-  all-reduce per step (head: 8.4 M floats; +41.9 M with LoRA).  The frozen 7B never enters a
-  collective: with ``use_orig_params`` torch FSDP would reduce-scatter 436 MB per layer of zeros.
-  Loss scaling: each rank backpropagates mse/world and lambda||W||^2/world, so the SUM over ranks is
-  the gradient of the single-process objective on the concatenated batch (penalty counted once).
+* ``ShardedFlatState``  - what trains (head, LoRA adapters; for the full fine-tune also the backbone store) lives in flat
+  buffers cut into segments; per step every segment's gradient is REDUCE-SCATTERED (started from the backward pass as
+  soon as the segment's layers are differentiated), each rank runs the clip + AdamW on its 1/world slice only (fp32
+  master and both moments exist only for the owned slice) and the refreshed bf16 copies are ALL-GATHERED back.  The
+  frozen 7B never enters a gradient collective: with ``use_orig_params`` torch FSDP would reduce-scatter 436 MB per
+  layer of zeros.  Loss scaling: each rank backpropagates mse/world and lambda||W||^2/world, so the SUM over ranks is
+  the gradient of the single-process objective on the concatenated batch (penalty counted once).  In FSDP's
+  vocabulary this is ZeRO-2 for the trained bf16 WEIGHTS of the full fine-tune (they stay replicated, 14 GB on a
+  288 GB card; gradients and optimiser state are sharded) and FULL_SHARD for the frozen ones when opted into:
 * ``ShardedLayerStore`` - the fsdp.yaml-equivalent parameter sharding for the frozen decoder layers:
   each rank keeps 1/world of every layer's flat bf16 weights (436 MB/layer -> 54.5 MB at 8 ranks);
   the full layer is all-gathered into one of two buffers on a side stream, one layer ahead of
   compute (forward and, in reverse order, backward).  On xGMI (point-to-point links) RCCL's
   all-gather moves each 54.5 MB shard over its own link, ~0.36 ms/layer, hidden behind ~2 ms of
   layer compute.  With 288 GB of HBM the replicated variant (no gathers) is the faster default;
-  sharding is opt-in (``shard_frozen=True``) for memory parity with the reference's FSDP intent.
+  sharding is opt-in (``shard_frozen=True``) for memory parity with the reference's FSDP intent.  Under
+  ``VLB_COMM=direct`` the gathers go through libvlb's own all-pairs schedule (``vlb_allgather_direct``).
 
 Everything here works on CPU tensors with the gloo backend (tests/test_cpu_parallel.py).
 """
@@ -227,11 +232,17 @@ def attach_data_parallel(module, optimizer, group=None, comm=None, force_collect
     return state
 
 
+_direct_comms = {}
+
+
 def make_comm(group=None):
-    """VLB_COMM=direct selects libvlb's own RCCL schedules (vlb_comm_*); default: torch.distributed."""
+    """VLB_COMM=direct selects libvlb's own RCCL schedules (vlb_comm_*); default: torch.distributed.  One DirectComm (one
+    RCCL communicator, one issue order) per process group: the gradient exchange and the frozen-layer gathers share it."""
     if os.environ.get("VLB_COMM", "torch") == "direct" and dist.is_initialized() and dist.get_backend(group) == "nccl":
         from .parallel_native import DirectComm
-        return DirectComm(group)
+        if group not in _direct_comms:
+            _direct_comms[group] = DirectComm(group)
+        return _direct_comms[group]
     return TorchComm(group)
 
 
@@ -273,8 +284,11 @@ def sync_module_states(module, src: int = 0, group=None):
 class ShardedLayerStore:
     """1/world shard of every layer's flat weights + double-buffered, prefetched all-gather."""
 
-    def __init__(self, layers: list[dict], keys: tuple, group=None, stream=None):
+    def __init__(self, layers: list[dict], keys: tuple, group=None, stream=None, comm=None):
+        """``comm``: a TorchComm / DirectComm whose ``all_gather`` does the per-layer gathers (``make_comm(group)`` by
+        default: ``VLB_COMM=direct`` puts the 436 MB-per-layer gathers on vlb_allgather_direct's all-pairs schedule)."""
         self.group = group
+        self.comm = comm
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.keys = keys
@@ -323,10 +337,12 @@ class ShardedLayerStore:
         self.in_buf[b] = i
 
     def _gather(self, out, shard):
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             out.copy_(shard)
-        else:
-            dist.all_gather_into_tensor(out, shard, group=self.group)
+            return
+        if self.comm is None:
+            self.comm = make_comm(self.group)
+        self.comm.all_gather(out[:shard.numel() * self.world], shard).wait()      # ordered on the calling (side) stream
 
     def get(self, i: int) -> dict:
         """Full weights of layer i as views into the gather buffer (valid until layer i+2 is fetched)."""

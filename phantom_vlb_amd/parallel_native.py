@@ -52,14 +52,17 @@ class DirectComm:
         return _W()
 
     def reduce_scatter(self, out, inp):
+        """fp32 (head / LoRA store) or bf16 (the full fine-tune's backbone store): slices travel in their own dtype and are
+        summed in rank order with fp32 accumulation by one local kernel."""
         n = out.numel()
-        assert inp.numel() == n * self.world and out.dtype == torch.float32 and inp.dtype == torch.float32
-        need = lib.vlb_reducescatter_stage_floats(n, self.world)
+        assert inp.numel() == n * self.world and out.dtype == inp.dtype and out.dtype in (torch.float32, torch.bfloat16)
+        bf16 = out.dtype == torch.bfloat16
+        fn = lib.vlb_reducescatter_direct_bf16 if bf16 else lib.vlb_reducescatter_direct
         self._enter()
         with torch.cuda.stream(self.stream):
-            stage = torch.empty(need, dtype=torch.float32, device=out.device)      # stream-ordered allocation on the side stream
-            check(lib.vlb_reducescatter_direct(self._h, inp.data_ptr(), out.data_ptr(), n, stage.data_ptr(),
-                                               self.stream.cuda_stream), "vlb_reducescatter_direct")
+            stage = torch.empty(n * self.world, dtype=out.dtype, device=out.device)      # stream-ordered allocation on the side stream
+            check(fn(self._h, inp.data_ptr(), out.data_ptr(), n, stage.data_ptr(), self.stream.cuda_stream),
+                  "vlb_reducescatter_direct_bf16" if bf16 else "vlb_reducescatter_direct")
         return self._handle()
 
     def all_gather(self, out, inp):

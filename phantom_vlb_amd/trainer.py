@@ -50,22 +50,33 @@ class LearningRateMonitor:
             trainer._log({"lr-AdamW": module.optimizer.param_groups[0]["lr"]})
 
 
-def trainable_state(module, step: int) -> dict:
+def trainable_state(module, step: int, to_host: bool = True) -> dict | None:
     """Everything a bit-exact resume needs, trainables only (head + LoRA / trained backbone tensors), gathered from
     the shards under data parallelism (a collective: call on every rank).  ``state_dict`` uses the upstream / peft
-    layouts (``lora_B.weight`` is [out, r]) so it can be handed to ``configure_model(state_dict=...)`` or to peft."""
+    layouts (``lora_B.weight`` is [out, r]) so it can be handed to ``configure_model(state_dict=...)`` or to peft.
+    ``to_host=False`` (every rank but the writer): take part in the gathers, build nothing, return None - the host
+    copies of a 7B full fine-tune's master and moments are 84 GB and only rank 0 writes the file."""
     opt = getattr(module, "optimizer", None)
-    sharded = getattr(module, "sharded", None)
-    if sharded is not None:
-        sharded.gather_masters()
-    sd = module.trainable_state_dict()
-    state = {"state_dict": sd, "global_step": step, "format": 2}
+    for sh in (getattr(module, "sharded", None), getattr(module, "sharded_backbone", None)):
+        if sh is not None:
+            sh.gather_masters()            # the optimiser updates the owned slices only: refresh the full-size masters
+    n_stores = len(opt.flats) if opt is not None else 0
+
+    def gathered(name, i=0):
+        t = opt.full_state(name, i)          # collective under data parallelism
+        return t.cpu() if to_host else None
+
+    state = {}
     if opt is not None:
-        state.update(exp_avg=opt.full_state("m").cpu(), exp_avg_sq=opt.full_state("v").cpu(), opt_step=opt.step_count,
-                     flat_offsets={n: (o, k) for n, (o, k, _) in module.flat.offsets.items()},
-                     lr=opt.param_groups[0]["lr"])
+        state.update(exp_avg=gathered("m"), exp_avg_sq=gathered("v"))
         # further flat stores (full fine-tune: the backbone in kernel layouts) travel whole: master + both moments
-        state["stores"] = [{k: opt.full_state(k, i).cpu() for k in ("master", "m", "v")} for i in range(1, len(opt.flats))]
+        state["stores"] = [{k: gathered(k, i) for k in ("master", "m", "v")} for i in range(1, n_stores)]
+    if not to_host:
+        return None
+    state.update(state_dict=module.trainable_state_dict(), global_step=step, format=2)
+    if opt is not None:
+        state.update(opt_step=opt.step_count, flat_offsets={n: (o, k) for n, (o, k, _) in module.flat.offsets.items()},
+                     lr=opt.param_groups[0]["lr"])
     sch = getattr(module, "scheduler", None)
     if sch is not None:
         state["lr_scheduler"] = sch.state_dict()
@@ -82,8 +93,9 @@ class TrainableCheckpoint:
         self.best = None
 
     def save(self, module, path, step):
-        state = trainable_state(module, step)       # gathers the shards: every rank takes part
-        if int(os.environ.get("RANK", "0")) != 0:
+        writer = int(os.environ.get("RANK", "0")) == 0
+        state = trainable_state(module, step, to_host=writer)       # gathers the shards: every rank takes part
+        if not writer:
             return                      # data parallel: rank 0 writes the one file
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         torch.save(state, path)
@@ -131,6 +143,21 @@ def load_trainable_checkpoint(module, path):
     return st.get("global_step", 0)
 
 
+def _iter_selected(loader, select=None, limit=None):
+    """(index, batch) of the batches with select(index) true, stopping in front of index ``limit``.  A DevicePrefetcher
+    stages only those (datamodule.DevicePrefetcher.iter_selected); a plain loader is simply filtered."""
+    if hasattr(loader, "iter_selected"):
+        return loader.iter_selected(select, limit)
+
+    def gen():
+        for i, b in enumerate(loader):
+            if limit is not None and i >= limit:
+                return
+            if select is None or select(i):
+                yield i, b
+    return gen()
+
+
 class Trainer:
     def __init__(self, precision="bf16-mixed", accelerator="gpu", gradient_clip_val=1.0, devices=1, num_nodes=1,
                  max_epochs=1, max_steps=-1, val_check_interval=1.0, log_every_n_steps=50, logger=None, callbacks=None,
@@ -172,11 +199,8 @@ class Trainer:
         self._cb("on_validation_epoch_start", model)
         tot, n = None, 0                     # summed on the device: one host sync per validation epoch, not per batch
         strided = self.world > 1 and getattr(model.backbone, "store", None) is None
-        for bi, batch in enumerate(loader):
-            if self.limit_val_batches is not None and bi >= self.limit_val_batches:
-                break
-            if strided and bi % self.world != self.rank:
-                continue
+        mine = (lambda bi: bi % self.world == self.rank) if strided else None
+        for bi, batch in _iter_selected(loader, mine, self.limit_val_batches):
             out = model.validation_step(batch)
             self._cb("on_validation_batch_end", model, out, batch, bi)
             tot = out["loss"].detach().double() if tot is None else tot + out["loss"].detach().double()
@@ -191,7 +215,7 @@ class Trainer:
             tot, n = t[0], int(t[1].item())
             for c in self.callbacks:
                 if hasattr(c, "all_reduce_sums"):
-                    c.all_reduce_sums()
+                    c.all_reduce_sums(model)         # every rank takes part, also one that drew no batch
         self._cb("on_validation_epoch_end", model)
         metrics = {"val/brain_loss": (float(tot) if tot is not None else 0.0) / max(n, 1)}
         metrics.update({k: float(v) for k, v in getattr(model, "logged", {}).items() if k.startswith("val_corr_avg")})
@@ -224,8 +248,9 @@ class Trainer:
             from .datamodule import DevicePrefetcher
             # ... and start the frozen vision side of batch i+1 on a side stream under step i (VLBLitModule.prefetch_vision)
             hook = getattr(model, "prefetch_vision", None)
-            train_loader = DevicePrefetcher(train_loader, model.device, on_staged=hook)
-            val_loader = DevicePrefetcher(val_loader, model.device, on_staged=hook)
+            drop = getattr(model, "discard_prefetched_vision", None)
+            train_loader = DevicePrefetcher(train_loader, model.device, on_staged=hook, on_discard=drop)
+            val_loader = DevicePrefetcher(val_loader, model.device, on_staged=hook, on_discard=drop)
         n_batches = len(train_loader)
         val_every = max(1, int(n_batches * self.val_check_interval)) if self.val_check_interval <= 1 else int(self.val_check_interval)
         t0 = time.time()
@@ -234,21 +259,24 @@ class Trainer:
             if hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
             self._cb("on_train_epoch_start", model)
-            for bi, batch in enumerate(train_loader):
-                if epoch == start_epoch and bi < skip:
-                    continue                  # resumed mid-epoch: these batches were consumed before the checkpoint
-                self._cb("on_train_batch_start", model, batch, bi)
-                loss = model.training_step(batch)
-                opt.step()
-                sched.step()
-                self.global_step += 1
-                if self.global_step % self.log_every_n_steps == 0:
-                    self._log({"train/brain_loss": float(loss), "lr": opt.param_groups[0]["lr"], "epoch": epoch,
-                               "elapsed_s": time.time() - t0})
-                if (bi + 1) % val_every == 0:
-                    self.validate(model, val_loader)
-                if 0 < self.max_steps <= self.global_step:
-                    return
+            seen = (lambda bi: bi >= skip) if epoch == start_epoch and skip else None     # resumed mid-epoch: the batches
+            batches = _iter_selected(train_loader, seen, None)                            # before the checkpoint are not staged
+            try:
+                for bi, batch in batches:
+                    self._cb("on_train_batch_start", model, batch, bi)
+                    loss = model.training_step(batch)
+                    opt.step()
+                    sched.step()
+                    self.global_step += 1
+                    if self.global_step % self.log_every_n_steps == 0:
+                        self._log({"train/brain_loss": float(loss), "lr": opt.param_groups[0]["lr"], "epoch": epoch,
+                                   "elapsed_s": time.time() - t0})
+                    if (bi + 1) % val_every == 0:
+                        self.validate(model, val_loader)
+                    if 0 < self.max_steps <= self.global_step:
+                        return
+            finally:
+                batches.close()              # a batch staged ahead but never consumed is dropped (DevicePrefetcher.on_discard)
         return
 
     def save_checkpoint(self, filepath, weights_only: bool = False):

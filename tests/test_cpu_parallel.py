@@ -165,3 +165,41 @@ def _store(rank, world):
 def test_sharded_layer_store_roundtrip():
     out = _run(_store)
     assert out[0] and out[1]
+
+
+def _validate_with_an_idle_rank(rank, world):
+    """Rank-strided validation with fewer batches than ranks (limit_val_batches=1 at world 2): rank 1 draws nothing and
+    must still issue the callback's collectives - the Pearson sums and the loss agree on both ranks afterwards."""
+    from phantom_vlb_amd.trainer import Trainer
+    from phantom_vlb_amd.utils import LogValAccuracyCallback
+
+    class _Cfg:
+        num_target = 5
+
+    class _Model:
+        config, device, backbone = _Cfg(), torch.device("cpu"), object()
+
+        def __init__(self):
+            self.logged = {}
+
+        def log(self, k, v, **kw):
+            self.logged[k] = v
+
+        def validation_step(self, batch):
+            return {"loss": batch["y"].pow(2).mean(), "brain_preds": batch["p"], "brain_vals": batch["y"]}
+
+    gen = torch.Generator().manual_seed(7)
+    batches = [{"p": torch.randn(6, 5, generator=gen), "y": torch.randn(6, 5, generator=gen)} for _ in range(3)]
+    cb = LogValAccuracyCallback()
+    tr = Trainer(callbacks=[cb], limit_val_batches=1, devices=world)
+    m = _Model()
+    metrics = tr.validate(m, batches)
+    ref = torch.stack([torch.corrcoef(torch.stack([batches[0]["p"][:, i], batches[0]["y"][:, i]]))[0, 1] for i in range(5)])
+    return {"loss": metrics["val/brain_loss"], "corr": cb.correlations.clone(), "n": cb.n,
+            "err": float((cb.correlations - ref).abs().max()), "want": float(batches[0]["y"].pow(2).mean())}
+
+
+def test_validation_with_fewer_batches_than_ranks_keeps_collectives_aligned():
+    r = _run(_validate_with_an_idle_rank)
+    assert r[0]["n"] == r[1]["n"] == 6 and torch.equal(r[0]["corr"], r[1]["corr"])
+    assert r[0]["err"] < 1e-5 and abs(r[0]["loss"] - r[0]["want"]) < 1e-6 and r[0]["loss"] == r[1]["loss"]

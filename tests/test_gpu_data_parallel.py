@@ -129,6 +129,22 @@ def _worker_full(rank, world, port, ret):
         torch.cuda.synchronize()
         out = {"master": m.full.flat.master.cpu(), "compute": m.full.flat.compute.float().cpu(),
                "wt_ok": bool(torch.equal(m.backbone.w.layers[1]["wdown_t"], m.backbone.w.layers[1]["wdown"].t()))}
+        # checkpoint state under data-parallel full fine-tuning: the upstream-named state_dict must hold the UPDATED backbone
+        # weights (the optimiser writes the shard buffers; trainable_state gathers them first), it must agree with the flat
+        # `stores` copy, and only the writing rank builds host copies
+        from phantom_vlb_amd.trainer import trainable_state
+        m.full.flat.master.zero_()                      # stale staging area: whatever survives must come from the shards
+        state = trainable_state(m, 1, to_host=rank == 0)
+        if rank == 0:
+            f = m.full.flat
+            store = state["stores"][0]["master"]
+            o, k, shp = f.offsets["layers.1.wdown"]
+            out["ckpt_ok"] = bool(torch.equal(state["state_dict"]["model.layers.1.mlp.down_proj.weight"], store[o:o + k].view(shp)))
+            out["ckpt_moved"] = bool((state["state_dict"]["model.layers.1.mlp.down_proj.weight"]
+                                      != p["model.layers.1.mlp.down_proj.weight"]).any())
+            out["ckpt_master"] = bool(torch.equal(store, out["master"]))
+        else:
+            out["ckpt_none"] = state is None
         if rank == 0:
             ref, ropt = build()
             ref.training_step(full)
@@ -154,6 +170,7 @@ def test_two_rank_full_finetune_matches_single_process(dev):
     assert ret[0]["perr"] < 2.5e-3
     assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
     assert ret[0]["wt_ok"] and ret[1]["wt_ok"]
+    assert ret[0]["ckpt_ok"] and ret[0]["ckpt_moved"] and ret[0]["ckpt_master"] and ret[1]["ckpt_none"]
 
 
 def test_bench_gpus_2_launches_two_ranks(dev):

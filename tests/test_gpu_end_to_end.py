@@ -143,8 +143,7 @@ def test_vision_prefetch_is_bit_identical_and_consumed_once(dev):
     bb.prefetch_video_tokens(batch["vision"])
     batch["vision"].mul_(1.0)                               # in-place touch: the queued entry no longer describes this tensor
     again = bb.video_tokens(batch["vision"])
-    assert len(bb._vis_queue) == 1 and torch.equal(again, inline)
-    bb._vis_queue.clear()
+    assert len(bb._vis_queue) == 0 and torch.equal(again, inline)     # the stale entry is dropped at the lookup, result computed in line
     l0 = float(m.training_step(batch))
     m.prefetch_vision(batch)                                # deferred; its own step comes first -> computed in line, once
     assert len(bb._vis_pending) == 1 and not bb._vis_queue

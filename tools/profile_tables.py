@@ -1,6 +1,8 @@
 """Turn rocprofv3 outputs of `bench.py` into the tables committed under profiles/.
 
-  python tools/profile_tables.py stats  <kernel-trace dir> <steps incl. warmup> <out prefix> [note]     # per-kernel table + roofline column
+  python tools/profile_tables.py stats  <kernel-trace dir> <timed steps> <out prefix> [note]     # per-kernel table + roofline column;
+                                                       # only the dispatches between bench.py's two vlb_profile_marker_kernel launches
+                                                       # (the timed steps: no model construction, no warm-up) are counted
   python tools/profile_tables.py sq     <pmc dir> <out csv>                                      # SQ counters per kernel
   python tools/profile_tables.py traffic <fetch dir> <write dir> <out csv>                       # gate/up GEMM call: main + split-K tail + reduce
 
@@ -29,12 +31,32 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:64]
 
 
+def timed_window(tr):
+    """Dispatches of the kernel trace between bench.py's two marker launches (sorted by start time), or None."""
+    marks = [r for r in tr if "vlb_profile_marker_kernel" in r["Kernel_Name"]]
+    if len(marks) < 2:
+        return None
+    lo, hi = int(marks[0]["End_Timestamp"]), int(marks[-1]["Start_Timestamp"])
+    return [r for r in tr if int(r["Start_Timestamp"]) >= lo and int(r["End_Timestamp"]) <= hi]
+
+
 def stats(d, steps, prefix, note=""):
-    f = max(glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
-    rs = list(csv.DictReader(open(f)))
+    t = max(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    tr = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
+    win = timed_window(tr)
+    scope = f"the {steps} timed steps only (dispatches between bench.py's two vlb_profile_marker_kernel launches: no model construction, no warm-up)"
+    if win is None:
+        win, scope = tr, f"WHOLE trace (no markers found): {steps} steps assumed, model init included"
+    acc = {}
+    for r in win:
+        a = acc.setdefault(r["Kernel_Name"], [0, 0.0])
+        a[0] += 1
+        a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    rs = [{"Name": k, "Calls": v[0], "TotalDurationNs": v[1], "AverageNs": v[1] / v[0]} for k, v in acc.items()]
+    rs.sort(key=lambda r: -r["TotalDurationNs"])
     tot = sum(float(r["TotalDurationNs"]) for r in rs)
     with open(f"profiles/{prefix}_kernel_table.csv", "w") as o:
-        o.write(f"# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps {steps - 2} --warmup 2 --no-cpu-baseline` ({steps} steps in the trace, model init included); "
+        o.write(f"# rocprofv3 --kernel-trace of `python3 bench.py --steps {steps} ...`; {scope}; "
                 "achieved = algorithmic work per call (tools/profile_tables.py WORK) / avg duration; frac = achieved / (8 TB/s | 2.5 PFLOP/s)" + (f"; {note}" if note else "") + "\n")
         o.write("kernel,calls_per_step,avg_us,ms_per_step,pct_of_kernel_time,bound,achieved,unit,frac_of_peak\n")
         for r in rs:
@@ -70,13 +92,12 @@ def stats(d, steps, prefix, note=""):
         elif "norm" in n: groups["norms"] += t
         else: groups["other"] += t
     with open(f"profiles/{prefix}_kernel_groups.txt", "w") as o:
-        o.write(f"kernel time {tot / 1e6 / steps:.1f} ms/step over {steps} traced steps (incl. 2 warm-up steps and model init)" + (f"; {note}" if note else "") + "\n")
+        o.write(f"kernel time {tot / 1e6 / steps:.1f} ms/step; {scope}" + (f"; {note}" if note else "") + "\n")
         for k, v in groups.items():
             o.write(f"  {k:16s} {100 * v / tot:5.1f} %  {v / 1e6 / steps:6.1f} ms/step\n")
     print(open(f"profiles/{prefix}_kernel_groups.txt").read())
-    # gate/up call from the trace
-    t = max(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
-    tr = sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"]))
+    # gate/up call from the trace (timed steps only)
+    tr = win
     w4 = [r for r in tr if re.search(r"gemm_w4_kernel<8, 0, 8, false, false>", r["Kernel_Name"])]
     if not w4:
         return
@@ -162,6 +183,13 @@ def traffic(dfetch, dwrite, out):
             o.write(f"{c},{g},{n},{a:.1f},{b:.1f}\n")
         o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} (A|t + W|B + saved [gate|up] [M,N] + h [M,N/2], bf16); ratio {total / alg:.2f}\n")
     print(open(out).read())
+    # the tracked shape -> bytes table bench.py reads its roofline.traffic from
+    import json
+    jp = "profiles/gateup_traffic.json"
+    tab = json.load(open(jp)) if os.path.exists(jp) else {}
+    tab[f"{M},{2 * FF},{E}"] = {"bytes": float(f"{total:.4e}"), "source": out,
+                               "what": "configs[2] default bench (LoRA, packed rows): vlb_gemm_swiglu_save call = main launch + split-K tail + reduce"}
+    json.dump(tab, open(jp, "w"), indent=1)
 
 
 if __name__ == "__main__":
