@@ -13,15 +13,31 @@ import re
 
 import yaml
 
-# Lightning `_target_`s of the reference's YAML are ALWAYS routed to the built-in runner, whether or not Lightning is
-# installed: VLBLitModule's backward is explicit (no autograd graph), which Lightning's fit loop cannot drive
-# (automatic optimisation calls loss.backward(); manual optimisation rejects `gradient_clip_val`).  INTEGRATION.md.
+# Lightning `_target_`s of the reference's YAML.  With Lightning installed they are instantiated as written (VLBLitModule is a
+# LightningModule then and bridges its explicit backward to the automatic-optimisation loop, litmodule._ExplicitLoss);
+# without it - this container, the GPU boxes - or with VLB_TRAINER=builtin they go to the built-in runner, which honours
+# the same keys.
 ROUTED_TARGETS = {
     "lightning.pytorch.Trainer": "phantom_vlb_amd.trainer.Trainer",
     "lightning.pytorch.loggers.CSVLogger": "phantom_vlb_amd.trainer.CSVLogger",
     "lightning.pytorch.callbacks.LearningRateMonitor": "phantom_vlb_amd.trainer.LearningRateMonitor",
     "lightning.pytorch.callbacks.ModelCheckpoint": "phantom_vlb_amd.trainer.TrainableCheckpoint",
 }
+
+
+def use_builtin_trainer() -> bool:
+    """True when the YAML's Lightning targets must be served by phantom_vlb_amd.trainer: Lightning is not importable, or
+    VLB_TRAINER=builtin asks for it (VLB_TRAINER=lightning insists on the real one and fails loudly without it)."""
+    want = os.environ.get("VLB_TRAINER", "auto")
+    if want == "builtin":
+        return True
+    try:
+        import lightning.pytorch  # noqa: F401
+        return False
+    except Exception:
+        if want == "lightning":
+            raise
+        return True
 
 
 def _merge(a: dict, b: dict) -> dict:
@@ -116,5 +132,7 @@ def instantiate(node, **extra):
     kwargs = {k: instantiate(v) for k, v in node.items() if k != "_target_"}
     kwargs.update(extra)
     target = str(node["_target_"]).strip()
-    cls = _locate(ROUTED_TARGETS.get(target, target))
+    if target in ROUTED_TARGETS and use_builtin_trainer():
+        target = ROUTED_TARGETS[target]
+    cls = _locate(target)
     return cls(**kwargs)

@@ -22,12 +22,15 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 
-class _Base:
-    """Stand-in for ``lightning.pytorch.LightningDataModule``: the built-in Trainer only calls ``train_dataloader`` /
-    ``val_dataloader`` (see litmodule._Base for why the real Lightning classes are never subclassed)."""
+try:                                   # a LightningDataModule when Lightning is installed (reference datamodule :156), so the
+    from lightning.pytorch import LightningDataModule as _Base      # reference's train.py can pass it to Trainer.fit
+except Exception:
+    class _Base:
+        """Stand-in for ``lightning.pytorch.LightningDataModule`` where Lightning is absent: the built-in Trainer only calls
+        ``train_dataloader`` / ``val_dataloader``."""
 
-    def __init__(self):
-        pass
+        def __init__(self):
+            pass
 
 MODS_T = ("timeseries", "vision", "language")
 MODS_N = ("padvals", "vis_weights", "lang_weights")

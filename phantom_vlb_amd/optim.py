@@ -73,7 +73,10 @@ class VlbAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:               # Lightning's automatic optimisation: training_step + zero_grad + backward
+            with torch.enable_grad():
+                loss = closure()
         group = self.param_groups[0]
         self.step_count += 1
         st = _stream()

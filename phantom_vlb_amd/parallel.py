@@ -273,7 +273,7 @@ def sync_module_states(module, src: int = 0, group=None):
                 module.sharded_backbone.load_masters()
             full.refresh_transposed()
     else:
-        broadcast_parameters(module.parameters(), src, group)
+        broadcast_parameters([p.data for p in module.parameters()], src, group)
         for n, t in module.head.master.items():
             module.head.compute[n].copy_(t)
     lora = getattr(module, "lora", None)

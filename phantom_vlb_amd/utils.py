@@ -13,9 +13,12 @@ from . import ops  # noqa: F401
 from ._lib import check, lib
 
 
-class _Callback:
-    """Hook-name compatible stand-in for ``lightning.pytorch.callbacks.Callback`` (the built-in Trainer calls hooks by
-    name; the real base class is never needed - see litmodule._Base)."""
+try:                                   # a real Callback when Lightning is installed: its Trainer calls every hook by name
+    from lightning.pytorch.callbacks import Callback as _Callback
+except Exception:
+    class _Callback:
+        """Hook-name compatible stand-in for ``lightning.pytorch.callbacks.Callback`` (the built-in Trainer calls the hooks
+        that exist, by name)."""
 
 
 def get_hrf_weight(time_diff: float) -> float:

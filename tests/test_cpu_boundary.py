@@ -1,5 +1,5 @@
-"""Host-side boundary checks that need no GPU: Lightning `_target_`s are routed to the built-in runner even when a
-`lightning` package is importable, `find_all_linear_names` restates the reference's walk (litmodule :36-55), the
+"""Host-side boundary checks that need no GPU: Lightning `_target_`s go to the real Lightning when it is importable (the
+module / datamodule / callback classes then subclass its bases) and to the built-in runner otherwise, `find_all_linear_names` restates the reference's walk (litmodule :36-55), the
 LR monitor / checkpoint callbacks the reference's train.py wires (train.py:20-30,58) exist under the built-in
 Trainer."""
 import os
@@ -12,72 +12,58 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture
-def fake_lightning(tmp_path, monkeypatch):
-    """A minimal importable `lightning.pytorch` (Trainer, LightningModule, callbacks, loggers) on sys.path, whose
-    Trainer.fit does what the real one does in automatic optimisation: call loss.backward()."""
-    pkg = tmp_path / "lightning"
-    (pkg / "pytorch" / "callbacks").mkdir(parents=True)
-    (pkg / "pytorch" / "loggers").mkdir(parents=True)
-    (pkg / "__init__.py").write_text("")
-    (pkg / "pytorch" / "__init__.py").write_text(textwrap.dedent('''
-        class LightningModule:
-            FAKE = True
-        class LightningDataModule:
-            FAKE = True
-        class Trainer:
-            FAKE = True
-            def __init__(self, **kw):
-                self.kw = kw
-            def fit(self, model, datamodule=None):
-                loss = model.training_step(next(iter(datamodule.train_dataloader())))
-                loss.backward()          # automatic optimisation: needs an autograd graph
-        def seed_everything(s):
-            pass
-    '''))
-    (pkg / "pytorch" / "callbacks" / "__init__.py").write_text(textwrap.dedent('''
-        class Callback:
-            FAKE = True
-        class ModelCheckpoint(Callback):
-            def __init__(self, **kw): self.kw = kw
-        class LearningRateMonitor(Callback):
-            def __init__(self, **kw): self.kw = kw
-    '''))
-    (pkg / "pytorch" / "loggers" / "__init__.py").write_text(textwrap.dedent('''
-        class CSVLogger:
-            FAKE = True
-            def __init__(self, **kw): self.kw = kw
-    '''))
-    monkeypatch.syspath_prepend(str(tmp_path))
-    for k in [k for k in sys.modules if k == "lightning" or k.startswith("lightning.")]:
-        monkeypatch.delitem(sys.modules, k)
-    import lightning.pytorch as lp
-    assert lp.Trainer.FAKE
-    yield lp
-    for k in [k for k in sys.modules if k == "lightning" or k.startswith("lightning.")]:
-        sys.modules.pop(k, None)
+def _run_with_fake_lightning(tmp_path, code, env_extra=None):
+    """Run `code` in a fresh interpreter that finds tests/fake_lightning's package as `lightning` (a clean process: the
+    package decides its base classes when it is imported)."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_lightning
+    root = fake_lightning.write(tmp_path / "site")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, ROOT, os.path.join(ROOT, "oracle")]))
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
 
 
-def test_lightning_targets_route_to_the_builtin_runner_even_when_lightning_is_importable(fake_lightning, tmp_path):
-    import importlib
+def test_with_lightning_installed_the_yaml_targets_and_base_classes_are_lightnings(tmp_path):
+    """Reference train.py:41-56 instantiates `lightning.pytorch.Trainer` from the YAML and hands it VLBLitModule /
+    VLBDataModule / LogValAccuracyCallback.  With a `lightning` package importable those targets are instantiated as
+    written and the three classes subclass Lightning's bases (Trainer.fit type-checks them); VLB_TRAINER=builtin still
+    selects the built-in runner."""
+    code = """
+        import os, sys
+        import lightning.pytorch as lp
+        from lightning.pytorch.callbacks import Callback
+        from phantom_vlb_amd import config as C, trainer as T
+        from src.litmodule import VLBLitModule
+        from src.datamodule import VLBDataModule
+        from src import LogValAccuracyCallback
+        assert issubclass(VLBLitModule, lp.LightningModule) and issubclass(VLBDataModule, lp.LightningDataModule)
+        assert issubclass(LogValAccuracyCallback, Callback)
+        cfg = C.load_config("config", ["experiment=VLB_vllama2_friends_lora", "subject=sub-01", "output_dir=/tmp/x"])
+        assert cfg["trainer"]["_target_"] == "lightning.pytorch.Trainer"          # the reference's YAML, unchanged
+        tr = C.instantiate(cfg["trainer"], logger=[], callbacks=[])
+        want_builtin = os.environ.get("VLB_TRAINER") == "builtin"
+        assert (type(tr) is T.Trainer) == want_builtin and (type(tr) is lp.Trainer) == (not want_builtin)
+        assert tr.gradient_clip_val == 1
+        lg = C.instantiate(cfg["cvs_logger"])
+        assert (type(lg) is T.CSVLogger) == want_builtin
+        print("OK", type(tr).__module__)
+    """
+    assert "OK lightning.pytorch" in _run_with_fake_lightning(tmp_path, code)
+    assert "OK phantom_vlb_amd.trainer" in _run_with_fake_lightning(tmp_path, code, {"VLB_TRAINER": "builtin"})
+
+
+def test_without_lightning_the_builtin_runner_serves_the_yaml(tmp_path):
     from phantom_vlb_amd import config as C, trainer as T
-    cfg = C.load_config(os.path.join(ROOT, "config"), ["experiment=VLB_vllama2_friends_lora", "subject=sub-01",
-                                                       f"output_dir={tmp_path}"])
-    assert cfg["trainer"]["_target_"] == "lightning.pytorch.Trainer"          # the reference's YAML, unchanged
+    assert C.use_builtin_trainer()              # this environment has no Lightning
+    cfg = C.load_config(os.path.join(ROOT, "config"), ["experiment=VLB_vllama2_friends_lora", "subject=sub-01", f"output_dir={tmp_path}"])
     tr = C.instantiate(cfg["trainer"], logger=[], callbacks=[])
-    assert type(tr) is T.Trainer and not hasattr(tr, "FAKE")
-    assert tr.gradient_clip_val == 1.0 and tr.max_epochs == cfg["trainer"]["max_epochs"]
-    lg = C.instantiate(cfg["cvs_logger"])
-    assert type(lg) is T.CSVLogger
+    assert type(tr) is T.Trainer and tr.gradient_clip_val == 1.0 and tr.max_epochs == cfg["trainer"]["max_epochs"]
+    assert type(C.instantiate(cfg["cvs_logger"])) is T.CSVLogger
     assert type(C.instantiate({"_target_": "lightning.pytorch.callbacks.LearningRateMonitor", "logging_interval": "epoch"})) \
         is T.LearningRateMonitor
-    # the module / datamodule / callback classes never take the Lightning base classes, importable or not
-    for mod in ("phantom_vlb_amd.litmodule", "phantom_vlb_amd.datamodule", "phantom_vlb_amd.utils"):
-        m = importlib.reload(importlib.import_module(mod))
-        for name in ("VLBLitModule", "VLBDataModule", "LogValAccuracyCallback"):
-            cls = getattr(m, name, None)
-            if cls is not None:
-                assert not any(getattr(b, "FAKE", False) for b in cls.__mro__), (mod, name)
 
 
 def test_train_py_wires_the_reference_callbacks():

@@ -196,3 +196,59 @@ def test_full_finetune_through_trainer_fit_and_exact_resume(dev, tmp_path):
     assert torch.equal(a.flat.master, b.flat.master)
     lw = b.backbone.w.layers[0]
     assert torch.equal(lw["wo_t"], lw["wo"].t())
+
+
+def test_lightning_automatic_optimisation_drives_the_module_bit_for_bit(dev, tmp_path):
+    """Reference train.py:41-56: `lightning.pytorch.Trainer(precision="bf16-mixed", gradient_clip_val=1).fit(litmodule,
+    datamodule)`.  With a `lightning` package importable (tests/fake_lightning: its Trainer.fit runs Lightning's
+    automatic-optimisation sequence training_step -> zero_grad -> loss.backward() -> configure_gradient_clipping ->
+    optimizer.step -> scheduler.step) VLBLitModule is a LightningModule and survives that loop: 4 steps with LoRA dropout and
+    head dropout on leave EXACTLY the parameters the built-in runner produces from the same seeds - and the loss handed to
+    `loss.backward()` carries a graph although the kernels have none."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_lightning
+    root = fake_lightning.write(tmp_path / "site")
+    code = r'''
+import torch
+import lightning.pytorch as lp
+from lightning.pytorch.callbacks import LearningRateMonitor
+from src.litmodule import VLBLitModule, VLBLitModuleConfig
+from src.datamodule import VLBDataModule, VLBDataModuleConfig
+from src import LogValAccuracyCallback
+from phantom_vlb_amd import trainer as T
+
+def cfg():
+    return VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=True, lora_r=16, lora_alpha=32, lora_dropout=0.1,
+                              dropout_rate=0.1, num_target=128, l2_lambda=1e-3, lr=1e-3, betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2,
+                              lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini")
+
+def dm():
+    return VLBDataModule(VLBDataModuleConfig(lazyload_path="synthetic:3x4", subject="sub-01", seasons=["s1"], delay=3, window=3,
+                                             random_state=1234, shuffle_val_data=False, batch_size=2, geometry="mini", num_target=128))
+
+a = VLBLitModule(cfg())
+assert isinstance(a, lp.LightningModule)
+ta = lp.Trainer(precision="bf16-mixed", gradient_clip_val=1, max_epochs=2, max_steps=4, callbacks=[LogValAccuracyCallback(), LearningRateMonitor()])
+ta.fit(model=a, datamodule=dm())
+assert ta.global_step == 4 and a.optimizer.step_count == 4 and a.optimizer.max_norm == 1.0
+assert "train/brain_loss" in ta.logged_metrics and all(l == l for l in ta.losses)
+# Lightning's zero_grad ran between training_step and backward: the gradients were re-attached by loss.backward()
+n, p = a.trainable_named_parameters()[-1]
+assert isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.data_ptr() == a.lora.grads[n].data_ptr()
+loss = a.training_step(a.transfer_batch_to_device(next(iter(dm().train_dataloader())), a.device))
+assert loss.requires_grad and loss.grad_fn is not None
+sd = a.state_dict()
+assert "ridge_layer.linear.weight" in sd and any(".lora_A." in k for k in sd) and not any("embed_tokens" in k for k in sd)
+
+b = VLBLitModule(cfg())
+tb = T.Trainer(precision="bf16-mixed", gradient_clip_val=1, max_epochs=2, max_steps=4, val_check_interval=1.0)
+tb.fit(b, dm())
+assert tb.global_step == 4
+# 4 optimiser steps each; `a` ran one extra training_step (no optimiser step) after its fit
+assert torch.equal(a.flat.master, b.flat.master) and torch.equal(a.flat.compute, b.flat.compute), "parameters differ"
+assert a.optimizer.param_groups[0]["lr"] == b.optimizer.param_groups[0]["lr"]
+print("BRIDGE_OK")
+'''
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, ROOT, os.path.join(ROOT, "oracle")]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "BRIDGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -1,10 +1,12 @@
 """Drop-in for the reference's train.py (train.py:1-70): same CLI
 ``python train.py experiment=<name> subject=<sub-XX>`` and the same YAML keys.
 
-The YAML is read by the built-in Hydra-subset loader (phantom_vlb_amd.config) and ``_target_:
-lightning.pytorch.Trainer`` is always routed to the built-in fit loop (phantom_vlb_amd.trainer) - also when
-Lightning is installed, because the module's backward pass is explicit.  Comet logging is
-optional: without ``comet_ml`` or credentials only the CSV logger is attached.
+The YAML is read by the built-in Hydra-subset loader (phantom_vlb_amd.config).  With Lightning installed,
+``_target_: lightning.pytorch.Trainer`` and the callbacks are the real ones (VLBLitModule / VLBDataModule /
+LogValAccuracyCallback then subclass the Lightning base classes, like the reference's; the reference's own unchanged
+train.py drives them the same way); without it - or with VLB_TRAINER=builtin - the built-in fit loop
+(phantom_vlb_amd.trainer) honours the same keys.  Comet logging is optional: without ``comet_ml`` or
+credentials only the CSV logger is attached.
 """
 from __future__ import annotations
 
@@ -17,9 +19,12 @@ sys.path.insert(0, ROOT)
 
 def train(config: dict) -> None:
     import torch
-    from phantom_vlb_amd.config import instantiate
-    from phantom_vlb_amd.trainer import LearningRateMonitor, TrainableCheckpoint
+    from phantom_vlb_amd.config import instantiate, use_builtin_trainer
     from src import LogValAccuracyCallback
+    if use_builtin_trainer():
+        from phantom_vlb_amd.trainer import LearningRateMonitor, TrainableCheckpoint
+    else:                                        # reference train.py:3-4,20-30: the real callbacks
+        from lightning.pytorch.callbacks import LearningRateMonitor, ModelCheckpoint as TrainableCheckpoint
 
     seed = int(config.get("random_state", 1234))
     torch.manual_seed(seed)                      # L.seed_everything(config.random_state), train.py:18
