@@ -258,6 +258,131 @@ class VLBLitModule(_Base):
 
     def _attach_gradients(self):
         """``.grad`` of every trainable Parameter <- the gradient buffer the explicit backward filled (aliases, no copies)."""
+        for n, p in self.trainable_named_parameters():
+            if n in self.head.grads:
+                p.grad = self.head.grads[n]
+            elif n.startswith("backbone."):
+                continue        # bf16 gradients (like the reference's bf16 parameters'): read them with self.full.flat.g_(name)
+            else:
+                p.grad = self.lora.grads[n]
+
+    def trainable_state_dict(self) -> dict:
+        """Trainables on the host under their upstream / peft names and layouts (LoRA B as [out, r], rank padding
+        removed): what checkpoints store and what ``configure_model(state_dict=...)`` / peft accept."""
+        sd = {n: self.head.master[n].detach().cpu().clone() for n in HEAD_PARAMS}
+        if self.lora is not None:
+            sd.update({n: t.cpu() for n, t in self.lora.state_dict().items()})
+        if self.full is not None:
+            sd.update(self.full.state_dict())
+        return sd
+
+    def load_trainable_state_dict(self, sd: dict) -> None:
+        """Inverse of ``trainable_state_dict`` into the fp32 masters; bf16 copies and derived layouts are rebuilt."""
+        for n in HEAD_PARAMS:
+            self.head.master[n].copy_(sd[n].to(self.device, torch.float32))
+            self.head.compute[n].copy_(self.head.master[n])
+        if self.lora is not None:
+            self.lora.load_state_dict(sd)
+        # full fine-tune: the backbone masters travel as the flat store itself (trainer.trainable_state 'stores')
+
+    # ------------------------------------------------------------------ dropout randomness (counter based)
+    def _dropout_seed(self) -> int:
+        """Head dropout seed of the current step: (init_seed, rank, step) - ranks draw different masks for their
+        clips and a resumed run continues the sequence from the restored step counter."""
+        x = (self.config.init_seed * 0x9E3779B1 + (self.rank + 1) * 0x7F4A7C15 + self._step * 0x85EBCA6B + 0x165667B1) & 0xFFFFFFFF
+        return x or 1
+
+    def rng_state(self) -> dict:
+        return {"head_step": self._step, "lora_step": None if self.lora is None else self.lora.step}
+
+    def set_rng_state(self, st: dict) -> None:
+        self._step = int(st.get("head_step", 0))
+        if self.lora is not None and st.get("lora_step") is not None:
+            self.lora.step = int(st["lora_step"])
+
+    # ------------------------------------------------------------------ pieces of the step
+    def make_weight_mask(self, pad_vals, vis_weights, lang_weights, lang_len, max_len):
+        """reference :178-203 - one launch; values rounded to bf16 like the reference's mask."""
+        g = self.geometry
+        feature_len = vis_weights.shape[1] * g.ds_grid * g.ds_grid + lang_len - 1
+        assert feature_len == max_len
+        dev = self.device
+        return ops.weight_mask(pad_vals.to(dev, torch.int64), vis_weights.to(dev, torch.float64),
+                               lang_weights.to(dev, torch.float64), g.ds_grid * g.ds_grid, max_len, round_bf16=True)
+
+    def _vision_tensor(self, x_video):
+        if isinstance(x_video, (list, tuple)):          # reference passes [(tensor, "video"), ...]
+            x_video = torch.stack([v[0] if isinstance(v, (list, tuple)) else v for v in x_video])
+        return x_video.to(self.device, torch.float32).contiguous()
+
+    def forward(self, x_video, x_lang, weight_mask, attention_mask=None, y=None, keep_scale=None, layout=None, ids_host=None):
+        """reference :229-256 -> (regression_output fp32 [B,V], l2_reg).  attention_mask is re-derived
+        on the device from the ids (ids != 0), exactly what the reference passes in (:271).
+        ``layout``: packed RowLayout from ``backbone.row_layout`` (rows without padded tails)."""
+        vis = self._vision_tensor(x_video)
+        ids = x_lang.to(self.device, torch.int64).contiguous()
+        B = ids.shape[0]
+        if self.lora is not None:        # eval mode keeps the adapters (peft eval: dropout off), like the reference's validation
+            hidden, key_mask = self.lora.forward(self.backbone, vis, ids, layout, train=self.training)
+        elif self.full is not None and self.training:      # full fine-tune: forward that keeps what backward needs
+            hidden, key_mask = self.full.forward(vis, ids, layout, ids_host=ids_host)
+        else:
+            hidden, key_mask = self.backbone.forward(vis, ids, layout=layout)
+        if y is None:
+            y = torch.zeros(B, self.config.num_target, dtype=torch.float32, device=self.device)
+        pred, terms = self.head.forward(hidden, weight_mask, y, keep_scale, layout)
+        self._loss_terms = terms
+        return pred, terms[1]
+
+    def _common_step(self, batch, train: bool):
+        cfg, g = self.config, self.geometry
+        dev = self.device
+        # unpadded (packed) rows, like the reference's flash-attn path; needs the ids on the host (no sync)
+        layout = self.backbone.row_layout(batch["language"], batch["padvals"]) if self.pack_tokens else None
+        x_lang = batch["language"].to(dev).long()
+        wm = self.make_weight_mask(batch["padvals"], batch["vis_weights"], batch["lang_weights"], x_lang.shape[1],
+                                   self.nnmodule.config.tokenizer_model_max_length)
+        y = batch["timeseries"].to(dev, torch.float32).to(torch.bfloat16).float().contiguous()   # reference :288
+        keep = None
+        if train and cfg.dropout_rate > 0:          # nn.Dropout(p) in training mode (reference :226,251)
+            keep = ops.dropout_keep_scale(x_lang.shape[0], g.dim, cfg.dropout_rate, self._dropout_seed(), dev)
+        ids_host = batch["language"] if batch["language"].device.type == "cpu" else None
+        pred, _ = self.forward(batch["vision"], x_lang, wm, y=y, keep_scale=keep, layout=layout, ids_host=ids_host)
+        return pred, y, self._loss_terms
+
+    def prefetch_vision(self, batch, ready_event=None):
+        """Start the frozen vision side (CLIP tower + STC connector) of a FUTURE batch on a side stream, so that it runs under
+        the current step's decoder work; the step that later receives this batch picks the result up (Backbone.video_tokens).
+        Full fine-tune: the connector trains, so only the CLIP tower runs ahead.  Called by DevicePrefetcher for batch i+1
+        before step i is issued."""
+        if "vision" not in batch or not batch["vision"].is_cuda:
+            return
+        # Deferred: the next training_step launches it right behind its forward pass, so the side stream runs under the BACKWARD
+        # pass (the skinny LoRA kernels and the GEMM tails leave CUs idle there; the forward's GEMMs do not, and the bench's
+        # dominant-kernel timing stays undisturbed).  A batch whose own step comes first is computed in line by that step.
+        self.backbone.defer_video_tokens(batch["vision"], ready_event, tower_only=self.full is not None)
+
+    def discard_prefetched_vision(self, batch=None):
+        """A batch announced through prefetch_vision will not be consumed (``None``: none of the announced ones will)."""
+        vis = None if batch is None else batch.get("vision")
+        if batch is None or torch.is_tensor(vis):
+            self.backbone.discard_video_tokens(vis)
+
+    def training_step(self, batch):
+        """reference :259-306.  Leaves gradients in ``.grad`` of the trainable masters."""
+        self.train(True)
+        self._step += 1
+        if self.lora is not None:
+            self.lora.rank = self.rank
+        pred, y, terms = self._common_step(batch, train=True)
+        self.backbone.launch_deferred_video_tokens()         # a future batch's frozen vision side: behind this forward, under this backward
+        need_dh = self.lora is not None or self.full is not None
+        inv_world = 1.0 / self.world_size
+        dh = self.head.backward(need_dhidden=need_dh, loss_scale=inv_world, l2_scale=inv_world)
+        if self.lora is not None:
+            self.lora.backward(self.backbone, dh)
+        elif self.full is not None:
+            self.full.backward(dh)
         self._attach_gradients()
         self.log("train/brain_loss", terms[2])
         # a scalar Lightning's automatic optimisation can call .backward() on (see _ExplicitLoss); float(loss) as before

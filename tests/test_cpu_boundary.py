@@ -109,3 +109,17 @@ def test_find_all_linear_names_on_a_torch_module_tree():
     names = find_all_linear_names(Model())
     assert names == sorted(["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"])
     assert find_all_linear_names(nn.Linear(2, 2)) == [""]          # like the reference: a root-level Linear has the empty name
+
+
+def test_litmodule_keeps_the_reference_hook_surface():
+    """Reference src/litmodule/videollama2_vlb_litmodule.py:160-379: the hooks Trainer.fit and train.py reach for, by name."""
+    import inspect
+    from src.litmodule import VLBLitModule, VLBLitModuleConfig
+    for name in ("configure_model", "make_weight_mask", "forward", "training_step", "validation_step", "configure_optimizers",
+                 "log", "parameters", "state_dict", "configure_gradient_clipping", "transfer_batch_to_device", "prefetch_vision"):
+        assert callable(getattr(VLBLitModule, name, None)), name
+    assert list(inspect.signature(VLBLitModule.training_step).parameters) == ["self", "batch"]        # no batch_idx (reference :259)
+    assert list(inspect.signature(VLBLitModule.validation_step).parameters) == ["self", "batch"]
+    fields = [f for f in VLBLitModuleConfig.__dataclass_fields__][:16]
+    assert fields == ["model_path", "freeze_backbone", "use_lora", "lora_r", "lora_alpha", "lora_dropout", "dropout_rate", "num_target",
+                      "l2_lambda", "lr", "betas", "eps", "weight_decay", "lr_scheduler_name", "last_epoch", "t_max"]
