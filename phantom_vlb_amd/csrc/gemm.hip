@@ -1285,15 +1285,27 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
     {
       const bool fits32 = a.wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31) &&
                           (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
+#ifdef VLB_TOOLS
+      const int abl192 = (g_variant >= 0x30 && g_variant < 0x40) ? (g_variant & 0xf) : 0;     // timing-only ablations of the 192-row kernel
+      const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant >= 0x30) && fits32 && K + K2 >= 4096;
+#else
       const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
+#endif
       const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
       TailPlan p256, p192;
       const bool use192 = plan_rows(M, N, K + K2, ws_ok && w4, p256, p192);
-      if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || use192)) {
+      if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || g_variant >= 0x30 || use192)) {
         GemmArgs hi = a;
         hi.tiles_m = tm192; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
         const int rem192 = tiles192 % cus;
         hi.grid = p192.mode ? tiles192 - rem192 : tiles192;
+#ifdef VLB_TOOLS
+        if (abl192 == 1) return launch_w4<8, 1, 6>(hi, s);       // results wrong by construction: whole-tile launches only
+        if (abl192 == 2) return launch_w4<8, 2, 6>(hi, s);
+        if (abl192 == 4) return launch_w4<8, 4, 6>(hi, s);
+        if (abl192 == 8) return launch_w4<8, 8, 6>(hi, s);
+        if (abl192 == 7) return launch_w4<8, 7, 6>(hi, s);
+#endif
         int rc = launch_w4<8, 0, 6>(hi, s);
         if (rc != VLB_OK || !p192.mode) return rc;
         GemmArgs lo = hi;

@@ -258,13 +258,13 @@ class VLBLitModule(_Base):
 
     def _attach_gradients(self):
         """``.grad`` of every trainable Parameter <- the gradient buffer the explicit backward filled (aliases, no copies)."""
+        masters = dict(self._named_masters())
         for n, p in self.trainable_named_parameters():
-            if n in self.head.grads:
-                p.grad = self.head.grads[n]
-            elif n.startswith("backbone."):
+            if n.startswith("backbone."):
                 continue        # bf16 gradients (like the reference's bf16 parameters'): read them with self.full.flat.g_(name)
-            else:
-                p.grad = self.lora.grads[n]
+            g = self.head.grads[n] if n in self.head.grads else self.lora.grads[n]
+            p.grad = g
+            masters[n].grad = g             # the plain master views (head.master[n], lora.master[n]) carry it too
 
     def trainable_state_dict(self) -> dict:
         """Trainables on the host under their upstream / peft names and layouts (LoRA B as [out, r], rank padding
@@ -385,7 +385,9 @@ class VLBLitModule(_Base):
             self.full.backward(dh)
         self._attach_gradients()
         self.log("train/brain_loss", terms[2])
-        # a scalar Lightning's automatic optimisation can call .backward() on (see _ExplicitLoss); float(loss) as before
+        if _LP is None:
+            return terms[2]          # no Lightning in this process: the plain loss value, as the built-in runner reads it
+        # a scalar Lightning's automatic optimisation can call .backward() on (see _ExplicitLoss)
         return _ExplicitLoss.apply(terms[2], self, *self.parameters())
 
     def validation_step(self, batch):
