@@ -1130,7 +1130,7 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
   if constexpr (BM == 256 && BN == 256) {
     if (!fits32 && (g_variant == 2 || (g_variant >= 0x20 && g_variant < 0x30))) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
     if (g_variant == 2) return launch_w4<8, 0>(a, s);
-    if (g_variant == 3 || g_variant == 4 || g_variant == 5) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
+    if (g_variant == 3 || g_variant == 4 || g_variant == 5 || g_variant == 6) {      // 4 (A/B only): four-wave main launch, 8-wave kernel for the re-cut tail
       if (fits32 && a.K + a.K2 >= 4096) return launch_w4<8, 0>(a, s);
       return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
     }
@@ -1141,9 +1141,9 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     if (g_variant == 0x28) return launch_w4<8, 8>(a, s);
   } else {
     if constexpr (BM == 256 && BN == 128) {
-      if ((g_variant == 2 || g_variant == 3 || g_variant == 5) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
+      if ((g_variant == 2 || g_variant == 3 || g_variant == 5 || g_variant == 6) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
     }
-    if (g_variant == 2 || g_variant == 3 || g_variant == 4 || g_variant == 5 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
+    if (g_variant == 2 || g_variant == 3 || g_variant == 4 || g_variant == 5 || g_variant == 6 || g_variant >= 0x20) return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
   }
   if (g_variant == 1 || (g_variant == 0 && a.act == VLB_ACT_SWIGLU_PAIR)) {
     return launch_pp<BM, BN, WM, WN, (BM + BN) / 64, 0, 0, 0>(a, s, LDS);
@@ -1287,13 +1287,16 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
                           (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
 #ifdef VLB_TOOLS
       const int abl192 = (g_variant >= 0x30 && g_variant < 0x40) ? (g_variant & 0xf) : 0;     // timing-only ablations of the 192-row kernel
-      const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant >= 0x30) && fits32 && K + K2 >= 4096;
+      const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant == 6 || g_variant >= 0x30) && fits32 && K + K2 >= 4096;    // 6 (A/B): never 192-row tiles
 #else
       const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
 #endif
       const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
       TailPlan p256, p192;
-      const bool use192 = plan_rows(M, N, K + K2, ws_ok && w4, p256, p192);
+      bool use192 = plan_rows(M, N, K + K2, ws_ok && w4, p256, p192);
+#ifdef VLB_TOOLS
+      if (g_variant == 6) use192 = false;
+#endif
       if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || g_variant >= 0x30 || use192)) {
         GemmArgs hi = a;
         hi.tiles_m = tm192; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
