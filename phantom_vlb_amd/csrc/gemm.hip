@@ -40,6 +40,7 @@ struct GemmArgs {
   // SWIGLU_PAIR only: when set, the pre-activations are ALSO stored, de-interleaved, as [gate | up] rows of N columns
   // (what a LoRA / full backward needs) - vlb_gemm_swiglu_save
   bf16* aux; int ldaux;
+  int stagger;              // tools build only (timing experiment): odd workgroups of the first round start this many 10-ns ticks late
   int wide;                 // C (and aux) rows 16-byte aligned: required by the four-wave kernels, which store 16 bytes per lane (store_pair16)
 };
 
@@ -718,6 +719,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 
   int m0, n0;
   const int ksplit = map_tile(p, BM, BN, m0, n0);
+#ifdef VLB_TOOLS
+  // timing experiment: de-synchronise the CUs (every workgroup of a launch otherwise starts, and reaches its epilogue's
+  // burst of memory traffic, at the same moment): odd workgroups of the first round of 256 wait p.stagger x 10 ns
+  if (p.stagger > 0 && blockIdx.x < 256 && (blockIdx.x & 8)) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)p.stagger) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -731,7 +740,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int srow = (lane >> 3), sslot = lane & 7;
   const int r0 = wave * 8 + srow;
   const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
-  const int rowA = m0 + r0, rowW = n0 + r0;
+  // (tools build, timing only: ABL bit 4 / 5 make every workgroup stage W / A panel 0 - operands that always hit in L2)
+  const int rowA = (ABL & 32) ? r0 : m0 + r0, rowW = (ABL & 16) ? r0 : n0 + r0;
   const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
   const int nk_all = p.K / BK + p.K2 / BK;
   // split-K tail: this workgroup walks K-tiles [kt_lo, kt_lo + nk) of the concatenated (pair 1 | pair 2) sequence
@@ -1042,6 +1052,7 @@ VLB_TUNABLE int g_force_tile = 0;   // 0: heuristic, 1: 256x256, 2: 256x128 (tun
 VLB_TUNABLE int g_tail_split = 1;   // split a mostly idle last wave of tiles into 256x128 tiles
 VLB_TUNABLE int g_tile_order = 3;   // GemmArgs::order: bit 0 column bands of 8, bit 1 XCD chunks dealt per round, bit 2 16x16 rounds (A/B: variant bits 10-12 XOR 3)
 VLB_TUNABLE int g_order_auto = 1;   // pick_order's shape rule (A/B: variant bit 13 disables it)
+VLB_TUNABLE int g_stagger = 0;      // tools: start delay (10-ns ticks) of half the first-round workgroups (timing experiment)
 VLB_TUNABLE int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
 
 // Tile order for a shape.  The order decides which operand is swept once and which is re-read once per band, i.e. which
@@ -1139,6 +1150,9 @@ int launch_tile(GemmArgs& a, hipStream_t s) {
     if (g_variant == 0x24) return launch_w4<8, 4>(a, s);
     if (g_variant == 0x27) return launch_w4<8, 7>(a, s);
     if (g_variant == 0x28) return launch_w4<8, 8>(a, s);
+    if (g_variant == 0x41) return launch_w4<8, 16>(a, s);    // W always from panel 0 (L2-resident)
+    if (g_variant == 0x42) return launch_w4<8, 32>(a, s);    // A always from panel 0
+    if (g_variant == 0x43) return launch_w4<8, 48>(a, s);    // both
   } else {
     if constexpr (BM == 256 && BN == 128) {
       if ((g_variant == 2 || g_variant == 3 || g_variant == 5 || g_variant == 6) && fits32 && a.K + a.K2 >= 4096) return launch_w4<4, 0>(a, s);
@@ -1264,6 +1278,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0; a.drop_thresh = 0; a.drop_key = 0; a.drop_scale = 1.f;
   a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = pick_order(M, N, K); a.aux = (bf16*)aux; a.ldaux = ldaux;
+  a.stagger = g_stagger;
   a.wide = ((uintptr_t)C % 16) == 0 && ldc % 8 == 0 && (!aux || (((uintptr_t)aux % 16) == 0 && ldaux % 8 == 0 && (N / 2) % 8 == 0));
   hipStream_t s = as_stream(stream);
   const bool vec_ok = (ldc % 4 == 0) && (!residual || ldr % 4 == 0) && (!aux || (ldaux % 4 == 0 && (N / 2) % 4 == 0)) &&
@@ -1287,7 +1302,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
                           (int64_t)M * lda2 < (1ll << 31) && (int64_t)N * ldw2 < (1ll << 31);
 #ifdef VLB_TOOLS
       const int abl192 = (g_variant >= 0x30 && g_variant < 0x40) ? (g_variant & 0xf) : 0;     // timing-only ablations of the 192-row kernel
-      const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant == 6 || g_variant >= 0x30) && fits32 && K + K2 >= 4096;    // 6 (A/B): never 192-row tiles
+      const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant == 6 || (g_variant >= 0x30 && g_variant < 0x40)) && fits32 && K + K2 >= 4096;    // 6 (A/B): never 192-row tiles
 #else
       const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
 #endif
@@ -1297,7 +1312,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
 #ifdef VLB_TOOLS
       if (g_variant == 6) use192 = false;
 #endif
-      if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || g_variant >= 0x30 || use192)) {
+      if (w4 && g_force_tile == 0 && tiles > cus && (g_variant == 5 || (g_variant >= 0x30 && g_variant < 0x40) || use192)) {
         GemmArgs hi = a;
         hi.tiles_m = tm192; hi.tiles_n = tn; hi.tile0 = 0; hi.split_n = 1;
         const int rem192 = tiles192 % cus;
@@ -1308,6 +1323,9 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
         if (abl192 == 4) return launch_w4<8, 4, 6>(hi, s);
         if (abl192 == 8) return launch_w4<8, 8, 6>(hi, s);
         if (abl192 == 7) return launch_w4<8, 7, 6>(hi, s);
+        if (abl192 == 9) return launch_w4<8, 16, 6>(hi, s);      // 0x39: W always from panel 0
+        if (abl192 == 10) return launch_w4<8, 32, 6>(hi, s);     // 0x3a: A always from panel 0
+        if (abl192 == 11) return launch_w4<8, 48, 6>(hi, s);     // 0x3b: both
 #endif
         int rc = launch_w4<8, 0, 6>(hi, s);
         if (rc != VLB_OK || !p192.mode) return rc;
@@ -1405,7 +1423,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.lda2 = lda2; a.ldw2 = ldw2;
   a.act = act; a.tiles_m = 0; a.tiles_n = 0; a.tile0 = 0; a.split_n = 1; a.grid = 0;
   a.ws = nullptr; a.k_splits = 0; a.tail_tiles = 0; a.order = pick_order(M, N, K); a.aux = nullptr; a.ldaux = 0;
-  a.wide = 1;
+  a.wide = 1; a.stagger = g_stagger;
   uint32_t t = (uint32_t)(drop_p * 65536.f + 0.5f);
   a.drop_thresh = t > 65535u ? 65535u : t;
   a.drop_key = lowbias32_h(seed);
@@ -1441,6 +1459,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
 
 #ifdef VLB_TOOLS
 // tuning hooks, libvlb_tools.so only: kernel variant / forced tile
+extern "C" void vlb_gemm_set_stagger(int ticks) { g_stagger = ticks; }
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;
