@@ -31,12 +31,7 @@ for K, G, p in [(4096, 3, 0.1), (4096, 1, 0.1), (4096, 2, 0.1), (14336, 1, 0.1),
     t = torch.zeros(M, PAD, dtype=BF, device=dev)
     dt = timeit(lambda: lora_down(x, A, R, 2.0, p, seeds3[:G], t))
     byt = M * K * 2 + R * K * 2 + M * R * 2
-    extra = ""
-    if p > 0:          # ... also storing the keep bits for the backward
-        tiles = torch.empty(lib.vlb_lora_keep_tiles_bytes(M, K, G), dtype=torch.uint8, device=dev)
-        dk = timeit(lambda: lora_down(x, A, R, 2.0, p, seeds3[:G], t, keep_tiles=tiles))
-        extra = f"   | storing keep bits: {dk*1e6:7.1f} us"
-    print(f"lora_down  K={K:5d} G={G} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s{extra}", flush=True)
+    print(f"lora_down  K={K:5d} G={G} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
 for K, G in [(4096, 3), (4096, 1), (4096, 2), (14336, 1)]:
     R = 16 * G
     u = torch.randn(M, PAD, device=dev).to(BF)
@@ -45,9 +40,7 @@ for K, G in [(4096, 3), (4096, 1), (4096, 2), (14336, 1)]:
     dx = torch.randn(M, K, device=dev).to(BF)
     dt = timeit(lambda: lora_dx_masked(u, At, dx, R, 0.1, seeds3[:G]))
     byt = 2 * M * K * 2 + M * R * 2
-    tiles = torch.randint(0, 255, (lib.vlb_lora_keep_tiles_bytes(M, K, G),), dtype=torch.uint8, device=dev)
-    dk = timeit(lambda: lora_dx_masked(u, At, dx, R, 0.1, seeds3[:G], keep_tiles=tiles))
-    print(f"lora_dx    K={K:5d} G={G}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s   | stored keep bits: {dk*1e6:7.1f} us  {byt/dk/1e12:5.2f} TB/s", flush=True)
+    print(f"lora_dx    K={K:5d} G={G}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
 for K, N, p in [(4096, 48, 0.1), (4096, 16, 0.1), (4096, 32, 0.1), (14336, 16, 0.1), (4096, 16, 0.0), (14336, 16, 0.0), (1024, 16, 0.0)]:
     Gm = torch.randn(M, PAD, device=dev).to(BF)
     X = torch.randn(M, K, device=dev).to(BF)
@@ -55,12 +48,7 @@ for K, N, p in [(4096, 48, 0.1), (4096, 16, 0.1), (4096, 32, 0.1), (14336, 16, 0
     ws = torch.empty(lib.vlb_wgrad_splits(M) * 48 * K, dtype=torch.float32, device=dev)
     dt = timeit(lambda: wgrad_skinny(Gm, X, dW, ws, N, p=p, seeds=seeds3[:N // 16] if p > 0 else None))
     byt = M * K * 2 + M * N * 2 + N * K * 4
-    extra = ""
-    if p > 0:
-        tiles = torch.randint(0, 255, (lib.vlb_lora_keep_tiles_bytes(M, K, N // 16),), dtype=torch.uint8, device=dev)
-        dk = timeit(lambda: wgrad_skinny(Gm, X, dW, ws, N, p=p, seeds=seeds3[:N // 16], keep_tiles=tiles))
-        extra = f"   | stored keep bits: {dk*1e6:7.1f} us  {byt/dk/1e12:5.2f} TB/s"
-    print(f"wgrad      K={K:5d} N={N} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s{extra}", flush=True)
+    print(f"wgrad      K={K:5d} N={N} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
 # dB^T + u fused (one pass over dy) vs the lora_down + wgrad pair
 from phantom_vlb_amd.lora import wgrad_skinny_u
 for K in (4096, 14336, 1024):
