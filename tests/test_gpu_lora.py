@@ -433,69 +433,3 @@ def test_mini_lora_other_ranks_match_oracle(dev, r, p):
     sd = m.trainable_state_dict()
     assert sd["model.layers.0.self_attn.k_proj.lora_A.weight"].shape == (r, g.dim)
     assert sd["model.layers.0.self_attn.k_proj.lora_B.weight"].shape == (g.kv_heads * g.head_dim, r)
-
-
-@pytest.mark.parametrize("M,K,G", [(200, 256, 1), (777, 512, 3), (5861, 4096, 3), (2573, 14336, 1), (1000, 1024, 2)])
-def test_stored_keep_bits_give_the_same_masks_as_the_hash(dev, M, K, G):
-    """vlb_lora_down writes the dropout keep bits it computed (1 bit per element and group); vlb_wgrad_skinny (dA) and
-    vlb_lora_dx_masked read them instead of hashing again: bit-identical results to the regenerated masks, and the stored bits
-    ARE the reference mask (numpy restatement of the hash) for every row, column and group."""
-    from phantom_vlb_amd._lib import lib
-    from phantom_vlb_amd.lora import lora_down, lora_dx_masked, wgrad_skinny
-    p, R = 0.1, 16 * G
-    x, A = _r(M, K, dev=dev), _r(R, K, dev=dev, scale=0.1)
-    seeds = [101 + 13 * g for g in range(G)]
-    nbytes = lib.vlb_lora_keep_tiles_bytes(M, K, G)
-    tiles = torch.full((nbytes,), 0xAA, dtype=torch.uint8, device=dev)
-    t0 = torch.zeros(M, 64, dtype=BF, device=dev)
-    t1 = torch.zeros(M, 64, dtype=BF, device=dev)
-    lora_down(x, A, R, 2.0, p, seeds, t0)
-    lora_down(x, A, R, 2.0, p, seeds, t1, keep_tiles=tiles)
-    assert torch.equal(t0, t1)                              # writing the bits does not change t
-    # decode the tiles: element (row, col) of group g = bit (fq&1)*16 + fr of dword (fq>>1)*8 + j of tile (row/16, col/32)
-    rt_cap, ks = (M + 31) // 32 * 2, K // 32
-    words = tiles.view(torch.int32).cpu().numpy().view(np.uint32).reshape(G, rt_cap, ks, 2, 8)
-    rows, cols = np.arange(M)[:, None], np.arange(K)[None, :]
-    fr, fq, j = rows & 15, (cols >> 3) & 3, cols & 7
-    for g in range(G):
-        w = words[g][rows >> 4, cols >> 5, fq >> 1, j]
-        got = (w >> ((fq & 1) * 16 + fr)) & 1
-        assert np.array_equal(got.astype(bool), keep_mask(seeds[g], M, K, p).numpy()), g
-    # dA = u^T keep(x) / (1-p): stored bits vs hash
-    u = _r(M, 64, dev=dev, seed=5)
-    ws = torch.empty(lib.vlb_wgrad_splits(M) * 48 * K, dtype=torch.float32, device=dev)
-    d0 = torch.empty(R, K, dtype=torch.float32, device=dev)
-    d1 = torch.empty(R, K, dtype=torch.float32, device=dev)
-    wgrad_skinny(u, x, d0, ws, R, p=p, seeds=seeds)
-    wgrad_skinny(u, x, d1, ws, R, p=p, seeds=seeds, keep_tiles=tiles)
-    assert torch.equal(d0, d1)
-    # dx += keep (u A) / (1-p)
-    if K % 64 == 0:
-        At = torch.zeros(K, 64, dtype=BF, device=dev)
-        At[:, :R] = A.t()
-        base = _r(M, K, dev=dev, seed=9)
-        x0, x1 = base.clone(), base.clone()
-        lora_dx_masked(u, At, x0, R, p, seeds)
-        lora_dx_masked(u, At, x1, R, p, seeds, keep_tiles=tiles)
-        assert torch.equal(x0, x1)
-
-
-def test_lora_step_with_stored_keep_bits_equals_the_rehashed_step(dev):
-    """A whole mini LoRA step (dropout 0.1): KEEP_TILES on and off give bit-identical losses and gradients."""
-    import phantom_vlb_amd.lora as L
-    from phantom_vlb_amd.litmodule import VLBLitModule
-    from phantom_vlb_amd.synthetic import synthetic_batch
-    m = VLBLitModule(_lora_cfg(p=0.1))
-    m.configure_model()
-    m.configure_optimizers()
-    batch = synthetic_batch(m.geometry, 3, seed=2)
-    out = []
-    try:
-        for flag in (True, False):
-            L.KEEP_TILES = flag
-            m.lora.step = 0
-            out.append((float(m.training_step(batch)), m.flat.grad.clone()))
-    finally:
-        L.KEEP_TILES = True
-    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
-    assert m.lora._kt_buf.numel() > 0
