@@ -256,22 +256,17 @@ int vlb_head_bwd(const void* hidden, const float* wmask, const void* ln1_w, cons
  * LoRA adapters (peft LoraConfig(r, lora_alpha, lora_dropout) + get_peft_model, litmodule :113-120):
  *   y = x W^T + s * B(A(dropout_p(x))),  s = alpha/r; only A [r,in] and B [out,r] train.
  * The base GEMM carries the adapter through vlb_gemm_bf16's second operand pair (A2 = t, W2 = B).
- * Dropout masks are counter-based hashes of (seed, row, column); every 16-rank group (= one adapted projection) has
- * its own seed (peft: one Dropout each).  The backward pass can regenerate them from the seeds (keep_tiles == NULL)
- * or read the keep bits the forward wrote: `keep_tiles` is a caller-owned buffer of
- * vlb_lora_keep_tiles_bytes(M, K, R/16) bytes, 64-byte aligned, opaque layout (1 bit per element and group), written
- * by vlb_lora_down and read by vlb_wgrad_skinny / vlb_lora_dx_masked called with the same M, K and group count -
- * the masks are identical either way (the integer hash made the multi-group kernels hash-bound, not HBM-bound).
+ * Dropout masks are counter-based hashes of (seed, row, column) - regenerated in backward, never
+ * stored; every 16-rank group (= one adapted projection) has its own seed (peft: one Dropout each).
  */
-int64_t vlb_lora_keep_tiles_bytes(int M, int K, int groups);
 /* t[M,R] = scale/(1-p) * keep(x) . A^T ; A: [R,K] bf16 (R = 16 * projections sharing x, <= 48);
- * seeds_host: R/16 host uint32 (may be NULL when drop_p == 0); keep_tiles: NULL or the buffer that receives the keep bits. */
+ * seeds_host: R/16 host uint32 (may be NULL when drop_p == 0). */
 int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M, int K, int R, float scale,
-                  float drop_p, const uint32_t* seeds_host, void* keep_tiles, void* stream);
+                  float drop_p, const uint32_t* seeds_host, void* stream);
 /* dx[M,K] += sum_g keep_g/(1-p) * (u[:, 16g:16g+16] . A_g) ; At: [K, >=R] bf16 (transposed adapters, row stride ldat).
- * K % 64 == 0, dx 16-byte aligned with lddx % 8 == 0.  keep_tiles: NULL (hash) or the forward's keep bits. */
+ * K % 64 == 0, dx 16-byte aligned with lddx % 8 == 0. */
 int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R, float drop_p,
-                       const uint32_t* seeds_host, const void* keep_tiles, void* stream);
+                       const uint32_t* seeds_host, void* stream);
 /* dB^T and u in one pass over dY (LoRA backward of one projection, rank 16):
  *   dW[16,K] (fp32) = alpha * G[:, :16]^T . X + beta * dW        (G = t, X = dY  ->  dB^T = t^T dY)
  *   u[m, 0:16] (bf16, row stride ldu) = u_scale * X[m,:] . Bt^T    (Bt = B^T [16,K] bf16  ->  u = s dY B)
@@ -298,11 +293,10 @@ int vlb_transpose16_scatter(const void* jobs, int n_jobs, void* stream);
  *   dW[N,K] (fp32) = alpha/(1-p) * sum_m G[m,n] * keep_g(X[m,k]) + beta * dW ;  N in {16,32,48}, g = n/16.
  * dA of all projections sharing x in one launch (G = [u_q|u_k|u_v], X = x, one dropout seed per
  * 16-rank group) and dB^T = t^T dY (G = t, X = dY, p = 0).  ws: fp32 [vlb_wgrad_splits(M), N, K]
- * partial slabs summed in a fixed order (reproducible).  seeds_host: N/16 host uint32, NULL if p == 0;
- * keep_tiles: NULL (hash) or the keep bits vlb_lora_down wrote for X (same M, K, N/16 groups; needs K % 32 == 0). */
+ * partial slabs summed in a fixed order (reproducible).  seeds_host: N/16 host uint32, NULL if p == 0. */
 int vlb_wgrad_splits(int M);
 int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
-                     float alpha, float beta, float drop_p, const uint32_t* seeds_host, const void* keep_tiles, void* stream);
+                     float alpha, float beta, float drop_p, const uint32_t* seeds_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser (litmodule :345-379 AdamW + CosineAnnealingLR; Trainer gradient_clip_val).

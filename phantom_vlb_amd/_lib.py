@@ -63,10 +63,9 @@ SIGNATURES = {
     "vlb_wgrad_skinny_u_multi": [P, I, P, I, I, I, P, P, P, P, F, F, F, P, I, P, P],
     "vlb_transpose16_scatter": [P, I, P],
     "vlb_wgrad_splits": [I],
-    "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P, P],
-    "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P, P],
-    "vlb_lora_keep_tiles_bytes": [I, I, I],
-    "vlb_lora_dx_masked": [P, I, P, I, P, I, I, I, I, F, P, P, P],
+    "vlb_wgrad_skinny": [P, I, P, I, P, P, I, I, I, F, F, F, P, P],
+    "vlb_lora_down": [P, I, P, P, I, I, I, I, F, F, P, P],
+    "vlb_lora_dx_masked": [P, I, P, I, P, I, I, I, I, F, P, P],
     "vlb_sumsq_ws_floats": [],
     "vlb_grad_sumsq": [P, L, P, P, P],
     "vlb_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
@@ -111,7 +110,7 @@ SIGNATURES = {
     "vlb_cast_f32_to_bf16": [P, P, L, P],
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
-_RESTYPES = {"vlb_last_error": c_char_p, "vlb_lora_keep_tiles_bytes": c_int64, "vlb_hrf_pool_ws_floats": c_int64, "vlb_ridge_ws_floats": c_int64, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
+_RESTYPES = {"vlb_last_error": c_char_p, "vlb_hrf_pool_ws_floats": c_int64, "vlb_ridge_ws_floats": c_int64, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
              "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64,
              "vlb_norm_bwd_ws_floats": c_int64, "vlb_rmsnorm_bwd_full_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
 

@@ -717,7 +717,7 @@ extern "C" int vlb_head_bwd(const void* hidden, const float* wmask, const void* 
     bf16* dpT = reinterpret_cast<bf16*>(dz16 + (int64_t)16 * E);   // [V][16] bf16
     hipLaunchKernelGGL(dpred_t_kernel, dim3((unsigned)(((int64_t)V * 16 + 255) / 256)), dim3(256), 0, st, pred, y, dpT, B, V, gscale);
     VLB_LAUNCH_CHECK();
-    int rc3 = vlb_wgrad_skinny(dpT, 16, ridge_w, E, dz16, wg_ws, V, 16, E, 1.f, 0.f, 0.f, nullptr, nullptr, stream);
+    int rc3 = vlb_wgrad_skinny(dpT, 16, ridge_w, E, dz16, wg_ws, V, 16, E, 1.f, 0.f, 0.f, nullptr, stream);
     if (rc3 != VLB_OK) return rc3;
     hipLaunchKernelGGL(head_dz_from16_kernel, dim3((E + 255) / 256, B), dim3(256), 0, st, dz16, keep_scale, dz_ws, E);
     VLB_LAUNCH_CHECK();

@@ -5,14 +5,9 @@
 //   vlb_lora_down       t[M,R]  = scale * (keep(x)/(1-p)) . A^T          (R = 16 * projections sharing x)
 //   vlb_lora_dx_masked  dx[M,K] += keep/(1-p) * (u . A)                   (backward through dropout)
 //   vlb_wgrad_skinny    dW[N,K] = alpha * G^T . (keep(X)/(1-p)) + beta*dW (dA and dB^T)
-// Dropout masks are counter-based (a 32-bit hash of (seed, row, column pair)); each 16-rank group has its own seed, like
-// peft's independent Dropout modules.  The hash is integer VALU work (~18 instructions per column pair) that made the
-// multi-group kernels hash-bound (1.4 TB/s with three groups), so the FORWARD (vlb_lora_down) can also write the keep
-// bits it computed - 1 bit per element and group, "keep tiles" - and the two backward consumers (vlb_wgrad_skinny's dA,
-// vlb_lora_dx_masked) read bits instead of hashing again; without a tile buffer (NULL) they regenerate the mask as before.
-// Keep-tile layout (private to this file): tile (rt, ks) = rows 16rt..16rt+15 x columns 32ks..32ks+31 of one group = 16 dwords;
-// element (row, col): fr = row & 15, fq = (col >> 3) & 3, j = col & 7  ->  dword (fq >> 1) * 8 + j, bit (fq & 1) * 16 + fr - the
-// 64-bit ballots of the producer's eight keep flags, split in halves; groups are `rt_cap * (K/32) * 16` dwords apart.
+// Dropout masks are counter-based (a 32-bit hash of (seed, row, column pair)), so forward and backward
+// regenerate the same mask and nothing is stored; each 16-rank group has its own seed, like peft's
+// independent Dropout modules.
 #include "common.hpp"
 
 namespace {
@@ -48,11 +43,6 @@ __device__ __forceinline__ void keep8(const Seeds& sd, int g, int64_t m, int K, 
   }
 }
 
-struct KeepTiles { uint32_t* p; int64_t gstride; int ks; };      // base, dwords per group, K / 32
-__device__ __forceinline__ uint32_t* keep_tile(const KeepTiles& kt, int g, int rt, int ks) {
-  return kt.p + g * kt.gstride + ((int64_t)rt * kt.ks + ks) * 16;
-}
-
 // ---------------------------------------------------------------- t = scale * drop(x) . A^T
 // one block = 32 rows of x (two MFMA row tiles share every adapter fragment); its 8 waves each take an
 // eighth of K with 4 k-steps of loads in flight, and the partial 16x16 tiles are summed through LDS in a
@@ -62,7 +52,7 @@ constexpr int LD_WAVES = 8;
 template <int G>   // number of 16-rank groups (projections sharing this x)
 __global__ __launch_bounds__(64 * LD_WAVES) void lora_down_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ A,
                                                         bf16* __restrict__ t, int ldt, int M, int K, float scale,
-                                                        uint32_t thresh, Seeds seeds, KeepTiles tiles) {
+                                                        uint32_t thresh, Seeds seeds) {
   __shared__ float red[LD_WAVES - 1][G][LD_RT][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16 * LD_RT;
@@ -99,17 +89,6 @@ __global__ __launch_bounds__(64 * LD_WAVES) void lora_down_kernel(const bf16* __
           keep8(seeds, g, m[r], K, k0 + fq * 8, thresh, keep);
 #pragma unroll
           for (int j = 0; j < 8; ++j) xm[j] = keep[j] ? xf[r][j] : (bf16)0.f;
-          if (tiles.p) {
-            // the eight compare results ARE the tile: ballot j = keep flag of column 8fq + j for the wave's 16 rows x 4 column
-            // groups (lane = 16fq + fr); lane l < 8 collects the low half of ballot l, lane 8 + l the high half: one 64-byte store
-            uint32_t mine = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const unsigned long long b = __ballot(keep[j]);
-              mine = lane == j ? (uint32_t)b : (lane == 8 + j ? (uint32_t)(b >> 32) : mine);
-            }
-            if (lane < 16) keep_tile(tiles, g, blockIdx.x * LD_RT + r, k0 >> 5)[lane] = mine;
-          }
         }
         acc[g][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], xm, acc[g][r], 0, 0, 0);
       }
@@ -151,7 +130,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void lora_down_kernel(const bf16* __
 template <int G>
 __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u, int ldu, const bf16* __restrict__ At, int ldat,
                                                       bf16* __restrict__ dx, int lddx, int M, int K, float inv_keep,
-                                                      uint32_t thresh, Seeds seeds, KeepTiles tiles) {
+                                                      uint32_t thresh, Seeds seeds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.y * 16;
   const int kbase = (blockIdx.x * 4 + wave) * 256;
@@ -182,16 +161,6 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
     for (int i = 0; i < 16; ++i) sum[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      // stored keep bits (forward's tiles): this lane's 16 columns kcol + 16fq .. +15 of row m are bits (t>>1)*16 + fr of the
-      // eight dwords of half fq & 1 of tile (m0/16, kcol/32 + fq/2): two 16-byte loads replace eight hashes
-      u32x4 kb0 = u32x4{}, kb1 = u32x4{};
-      if (tiles.p && thresh != 0) {
-        const uint32_t* tp_ = keep_tile(tiles, g, blockIdx.y, (kcol >> 5) + (fq >> 1)) + (fq & 1) * 8;
-        kb0 = *reinterpret_cast<const u32x4*>(tp_);
-        kb1 = *reinterpret_cast<const u32x4*>(tp_ + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { kb0[e] >>= fr; kb1[e] >>= fr; }
-      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         bf16x8 af = bf16x8{};
@@ -199,19 +168,12 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const bf16* __restrict__ u
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, uf[g], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         // lane holds columns kcol + 16fq + 4t + {0..3} of row m
         if (thresh != 0) {
-          if (tiles.p) {
-            const u32x4& kb = (t & 1) ? kb1 : kb0;           // dwords 4(t&1) + e
+          const int kk = kcol + 16 * fq + 4 * t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (!((kb[e] >> ((t >> 1) * 16)) & 1u)) d[e] = 0.f;
-          } else {
-            const int kk = kcol + 16 * fq + 4 * t;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const uint32_t h = drop_bits(seeds, g, m, K, (kk >> 1) + q);
-              if ((h & 0xffffu) < thresh) d[2 * q] = 0.f;
-              if ((h >> 16) < thresh) d[2 * q + 1] = 0.f;
-            }
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t h = drop_bits(seeds, g, m, K, (kk >> 1) + q);
+            if ((h & 0xffffu) < thresh) d[2 * q] = 0.f;
+            if ((h >> 16) < thresh) d[2 * q + 1] = 0.f;
           }
         }
 #pragma unroll
@@ -265,14 +227,11 @@ template <int G, bool WITH_U = false>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict__ Gm, int ldg, const bf16* __restrict__ X,
                                                          int ldx, float* __restrict__ ws, int M, int K,
                                                          int rows_per_split, uint32_t thresh, Seeds seeds,
-                                                         UProj up = UProj{}, float* __restrict__ upart = nullptr,
-                                                         KeepTiles tiles = KeepTiles{nullptr, 0, 0}) {
+                                                         UProj up = UProj{}, float* __restrict__ upart = nullptr) {
   constexpr int XT = WG_STEP * WG_COLS * 2;          // 16 KB
   constexpr int GT = WG_STEP * 16 * G * 2;           // 1 KB per group
-  constexpr int KT = WITH_U ? 0 : 1024 * G;          // stored keep bits of the tile: [group][2 row tiles][8 column tiles][64 B]
   constexpr int UT = WITH_U ? 2 * 4 * 2 * 4 * 64 * 4 : 0;     // [parity][wave][row tile][reg][lane] fp32 = 16 KB
-  constexpr int BUF = XT + GT + KT;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + UT];
+  __shared__ __attribute__((aligned(16))) char smem[2 * (XT + GT) + UT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = blockIdx.x * WG_COLS;
@@ -300,7 +259,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       if (lc >= pn) btf[ks] = bf16x8{};
     }
   }
-  float* ured = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* ured = reinterpret_cast<float*>(smem + 2 * (XT + GT));
 
   // staging: X piece i of this wave = rows 2*(4i+wave) + (lane>>5); 16-byte position pc = lane & 31.  The G tile (32 rows x
   // 16G columns, at most one 16-byte chunk per thread) goes through registers: its load is ISSUED in front of the X pieces
@@ -309,7 +268,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
   const int g_r = tid / (2 * G), g_ch = tid % (2 * G);
   const bool g_mine = tid < WG_STEP * 2 * G;
   auto stage = [&](int buf, int m0, bf16x8& gv) {
-    char* xb = smem + buf * BUF;
+    char* xb = smem + buf * (XT + GT);
     gv = bf16x8{};                               // rows beyond the split are zero: they contribute nothing
     if (g_mine && m0 + g_r < r1) gv = *reinterpret_cast<const bf16x8*>(Gm + (int64_t)(m0 + g_r) * ldg + g_ch * 8);
 #pragma unroll
@@ -320,17 +279,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       const int col = min(c0 + chunk * 8, K - 8);
       glds16_l(X + (int64_t)m * ldx + col, xb + piece * 1024);
     }
-    if constexpr (!WITH_U) {
-      // the forward's keep bits of this tile (one 1-KiB LDS-DMA piece per group, issued by wave g): lanes 0-31 fetch the
-      // 8 column tiles of row tile m0/16, lanes 32-63 those of the next one
-      if (tiles.p && wave < G) {
-        const int cd = min((c0 >> 5) * 16 + (lane & 31) * 4, tiles.ks * 16 - 4);         // dword inside the row tile's strip
-        glds16_l(keep_tile(tiles, wave, (m0 >> 4) + (lane >> 5), 0) + cd, xb + XT + GT + wave * 1024);
-      }
-    }
   };
   auto g_store = [&](int buf, const bf16x8& gv) {
-    if (g_mine) *reinterpret_cast<bf16x8*>(smem + buf * BUF + XT + g_r * 32 * G + g_ch * 16) = gv;
+    if (g_mine) *reinterpret_cast<bf16x8*>(smem + buf * (XT + GT) + XT + g_r * 32 * G + g_ch * 16) = gv;
   };
 
   const int nsteps = (r1 - r0 + WG_STEP - 1) / WG_STEP;
@@ -340,7 +291,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1, m0 = r0 + st * WG_STEP;
-    const char* xb = smem + cur * BUF;
+    const char* xb = smem + cur * (XT + GT);
     const char* gb = xb + XT;
     // ---- 1. every fragment of the current tile into registers (the compiler orders LDS accesses behind in-flight LDS-DMA
     // with vmcnt(0), so nothing may touch LDS between the issue of the next tile and the end of this step's math)
@@ -362,19 +313,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
       const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + ra * 512 + pa));
       const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(xb + rb * 512 + pb));
       xf[n] = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-    // keep bits of this lane's 8 rows (8fq .. 8fq+7 of the step) for its column of tile n: one byte of the staged strip
-    uint32_t mk[G][4];
-    if constexpr (!WITH_U) {
-      if (tiles.p && thresh != 0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const int off = (fq >> 1) * 512 + (wave * 2 + (n >> 1)) * 64 + (((n & 1) * 8 + (fr & 7)) << 2) + (fr >> 3) * 2 + (fq & 1);
-            mk[g][n] = *reinterpret_cast<const uint8_t*>(xb + XT + GT + g * 1024 + off);
-          }
-      }
     }
     bf16x8 xr[2][2];
     if constexpr (WITH_U) {
@@ -400,11 +338,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const bf16* __restrict_
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         bf16x8 xm = xf[n];
-        if (thresh != 0 && !WITH_U && tiles.p) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (!((mk[g][n] >> j) & 1u)) xm[j] = (bf16)0.f;
-        } else if (thresh != 0) {
+        if (thresh != 0) {
           // lanes fr and fr^1 hold the two columns of one hashed pair: the even lane hashes rows 0..3, the
           // odd lane rows 4..7, and they swap results (quad_perm [1,0,3,2]) - half the hashes per lane
           const bool odd = col & 1;
@@ -541,13 +475,6 @@ inline Seeds make_seeds(const uint32_t* seeds_host, int groups, int M, int K) {
   sd.fast = ((int64_t)M * (K >> 1) < (1ll << 32)) ? 1u : 0u;
   return sd;
 }
-inline KeepTiles make_tiles(void* keep_tiles, int M, int K) {
-  KeepTiles t;
-  t.p = static_cast<uint32_t*>(keep_tiles);
-  t.ks = K / 32;
-  t.gstride = (int64_t)((M + 31) / 32) * 2 * t.ks * 16;
-  return t;
-}
 inline uint32_t thresh16(float p) {
   if (p <= 0.f) return 0;
   uint32_t t = (uint32_t)(p * 65536.f + 0.5f);
@@ -560,19 +487,13 @@ extern "C" int vlb_wgrad_splits(int M) {
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
-extern "C" int64_t vlb_lora_keep_tiles_bytes(int M, int K, int groups) {
-  return (int64_t)((M + 31) / 32) * 2 * (K / 32) * 64 * groups;
-}
-
 extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
-                                float alpha, float beta, float drop_p, const uint32_t* seeds_host, const void* keep_tiles, void* stream) {
+                                float alpha, float beta, float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(G && X && dW && ws, "wgrad_skinny: null operand");
   VLB_REQUIRE(M > 0 && (N == 16 || N == 32 || N == 48) && K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ldg % 8 == 0,
               "wgrad_skinny: bad shape M=%d N=%d K=%d (N must be 16, 32 or 48)", M, N, K);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "wgrad_skinny: bad dropout arguments");
   VLB_REQUIRE((((uintptr_t)G | (uintptr_t)X) % 16) == 0, "wgrad_skinny: operands must be 16-byte aligned");
-  VLB_REQUIRE(!keep_tiles || (drop_p > 0.f && K % 32 == 0 && ((uintptr_t)keep_tiles % 64) == 0), "wgrad_skinny: keep tiles need drop_p > 0, K %% 32 == 0, 64-byte alignment");
-  const KeepTiles kt = make_tiles(const_cast<void*>(keep_tiles), M, K);
   hipStream_t st = as_stream(stream);
   const int splits = vlb_wgrad_splits(M);
   const int rps = (((M + splits - 1) / splits) + WG_STEP - 1) / WG_STEP * WG_STEP;
@@ -581,9 +502,9 @@ extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, 
   dim3 grid((K + WG_COLS - 1) / WG_COLS, splits);
   const uint32_t th = thresh16(drop_p);
   switch (N / 16) {
-    case 1: hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd, UProj{}, (float*)nullptr, kt); break;
-    case 2: hipLaunchKernelGGL(wgrad_mfma_kernel<2>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd, UProj{}, (float*)nullptr, kt); break;
-    default: hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd, UProj{}, (float*)nullptr, kt); break;
+    case 1: hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
+    case 2: hipLaunchKernelGGL(wgrad_mfma_kernel<2>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
+    default: hipLaunchKernelGGL(wgrad_mfma_kernel<3>, grid, dim3(256), 0, st, (const bf16*)G, ldg, (const bf16*)X, ldx, ws, M, K, rps, th, sd); break;
   }
   VLB_LAUNCH_CHECK();
   const int64_t nk = (int64_t)N * K;
@@ -594,45 +515,41 @@ extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, 
 }
 
 extern "C" int vlb_lora_down(const void* x, int ldx, const void* A, void* t, int ldt, int M, int K, int R, float scale,
-                             float drop_p, const uint32_t* seeds_host, void* keep_tiles, void* stream) {
+                             float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(x && A && t, "lora_down: null operand");
   VLB_REQUIRE(M > 0 && K % 32 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldx % 8 == 0 && ldt % 4 == 0,
               "lora_down: bad shape M=%d K=%d R=%d", M, K, R);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "lora_down: bad dropout arguments");
-  VLB_REQUIRE(!keep_tiles || (drop_p > 0.f && ((uintptr_t)keep_tiles % 64) == 0), "lora_down: keep tiles need drop_p > 0 and 64-byte alignment");
-  const KeepTiles kt = make_tiles(keep_tiles, M, K);
   const Seeds s = make_seeds(seeds_host, R / 16, M, K);
   const float sc = scale / (1.f - drop_p);
   dim3 grid((M + 16 * LD_RT - 1) / (16 * LD_RT));
   hipStream_t st = as_stream(stream);
   const uint32_t th = thresh16(drop_p);
   switch (R / 16) {
-    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s, kt); break;
-    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s, kt); break;
-    default: hipLaunchKernelGGL(lora_down_kernel<3>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s, kt); break;
+    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
+    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
+    default: hipLaunchKernelGGL(lora_down_kernel<3>, grid, dim3(64 * LD_WAVES), 0, st, (const bf16*)x, ldx, (const bf16*)A, (bf16*)t, ldt, M, K, sc, th, s); break;
   }
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
 
 extern "C" int vlb_lora_dx_masked(const void* u, int ldu, const void* At, int ldat, void* dx, int lddx, int M, int K, int R,
-                                  float drop_p, const uint32_t* seeds_host, const void* keep_tiles, void* stream) {
+                                  float drop_p, const uint32_t* seeds_host, void* stream) {
   VLB_REQUIRE(u && At && dx, "lora_dx_masked: null operand");
   VLB_REQUIRE(M > 0 && K % 64 == 0 && R % 16 == 0 && R >= 16 && R <= 48 && ldu % 8 == 0 && lddx % 8 == 0 && ldat % 8 == 0 && ldat >= R &&
                   ((uintptr_t)dx % 16) == 0,
               "lora_dx_masked: bad shape M=%d K=%d R=%d", M, K, R);
   VLB_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seeds_host), "lora_dx_masked: bad dropout arguments");
-  VLB_REQUIRE(!keep_tiles || (drop_p > 0.f && ((uintptr_t)keep_tiles % 64) == 0), "lora_dx_masked: keep tiles need drop_p > 0 and 64-byte alignment");
-  const KeepTiles kt = make_tiles(const_cast<void*>(keep_tiles), M, K);
   const Seeds s = make_seeds(seeds_host, R / 16, M, K);
   dim3 grid((K + 1023) / 1024, (M + 15) / 16);
   hipStream_t st = as_stream(stream);
   const uint32_t th = thresh16(drop_p);
   const float ik = 1.f / (1.f - drop_p);
   switch (R / 16) {
-    case 1: hipLaunchKernelGGL(lora_dx_kernel<1>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s, kt); break;
-    case 2: hipLaunchKernelGGL(lora_dx_kernel<2>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s, kt); break;
-    default: hipLaunchKernelGGL(lora_dx_kernel<3>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s, kt); break;
+    case 1: hipLaunchKernelGGL(lora_dx_kernel<1>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
+    case 2: hipLaunchKernelGGL(lora_dx_kernel<2>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
+    default: hipLaunchKernelGGL(lora_dx_kernel<3>, grid, dim3(256), 0, st, (const bf16*)u, ldu, (const bf16*)At, ldat, (bf16*)dx, lddx, M, K, ik, th, s); break;
   }
   VLB_LAUNCH_CHECK();
   return VLB_OK;

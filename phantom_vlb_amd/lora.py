@@ -28,8 +28,6 @@ from .geometry import Geometry
 BF16 = torch.bfloat16
 PAD = 64  # adapter rank columns padded to one GEMM K-tile
 FUSE_SWIGLU_BWD = True      # SwiGLU backward in the epilogue of the down projection's dgrad GEMM (A/B switch)
-KEEP_TILES = True           # the forward's vlb_lora_down stores the dropout keep bits, the backward's dA wgrad / lora_dx read them instead of
-                            # re-hashing (1 bit per element and projection: 0.9 GB for 32 layers at the LoRA batch; A/B switch, same masks)
 MERGE_DB_U = True           # one dB^T / u sweep for the projections sharing a dy (q|k|v, gate|up) instead of one each (A/B switch)
 
 
@@ -41,19 +39,17 @@ def _seeds(vals):
     return (ctypes.c_uint32 * len(vals))(*[v & 0xFFFFFFFF for v in vals])
 
 
-def lora_down(x, A, R, scale, p, seeds, out, keep_tiles=None):
-    """``keep_tiles``: uint8 buffer of >= vlb_lora_keep_tiles_bytes(M, K, R/16) bytes that receives the dropout keep bits."""
+def lora_down(x, A, R, scale, p, seeds, out):
     M, K = x.shape
     check(lib.vlb_lora_down(x.data_ptr(), x.stride(0), A.data_ptr(), out.data_ptr(), out.stride(0), M, K, R, scale, p,
-                            _seeds(seeds) if p > 0 else None, None if keep_tiles is None or p <= 0 else keep_tiles.data_ptr(), _stream()),
-          "vlb_lora_down")
+                            _seeds(seeds) if p > 0 else None, _stream()), "vlb_lora_down")
     return out
 
 
-def lora_dx_masked(u, At, dx, R, p, seeds, keep_tiles=None):
+def lora_dx_masked(u, At, dx, R, p, seeds):
     M, K = dx.shape
     check(lib.vlb_lora_dx_masked(u.data_ptr(), u.stride(0), At.data_ptr(), At.stride(0), dx.data_ptr(), dx.stride(0), M, K, R, p,
-                                 _seeds(seeds), None if keep_tiles is None else keep_tiles.data_ptr(), _stream()), "vlb_lora_dx_masked")
+                                 _seeds(seeds), _stream()), "vlb_lora_dx_masked")
 
 
 def wgrad_skinny_u(G, X, dW, ws, Bt, u_scale, u_out, u_ws, alpha=1.0, beta=0.0):
@@ -75,12 +71,11 @@ def wgrad_skinny_u_multi(G, X, cols, dWs, Bts, ws, u_scale, u_out, u_ws, alpha=1
           "vlb_wgrad_skinny_u_multi")
 
 
-def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seeds=None, keep_tiles=None):
+def wgrad_skinny(G, X, dW, ws, N, alpha=1.0, beta=0.0, p=0.0, seeds=None):
     """dW [N,K] fp32 (contiguous) = alpha/(1-p) * G[:, :N]^T keep(X) + beta*dW; N in {16,32,48}."""
     M, K = X.shape
     check(lib.vlb_wgrad_skinny(G.data_ptr(), G.stride(0), X.data_ptr(), X.stride(0), dW.data_ptr(), ws.data_ptr(), M, N, K,
-                               alpha, beta, p, _seeds(seeds) if p > 0 else None,
-                               None if keep_tiles is None or p <= 0 else keep_tiles.data_ptr(), _stream()), "vlb_wgrad_skinny")
+                               alpha, beta, p, _seeds(seeds) if p > 0 else None, _stream()), "vlb_wgrad_skinny")
 
 
 # (group name, [(target, out rows attr)], input) - projections in one group share their input
@@ -270,49 +265,29 @@ class LoraState:
             self._t_bufs = torch.zeros(len(self.layers), len(GROUPS), M, self._rpad_max(), dtype=BF16, device=self.dev)
         return self._t_bufs[li, gi, :M, :self.layers[li][GROUPS[gi][0]]["Rpad"]]
 
-    def _keep_tiles(self, li, gi, M, launch=0):
-        """Keep-bit buffer of (layer, group, 48-rank launch): written by the training forward's vlb_lora_down, read by that
-        step's backward.  One uint8 arena for all layers, grow-only with the packed row count; None when switched off."""
-        if not KEEP_TILES or self.p <= 0 or self.c != 1:
-            return None
-        if getattr(self, "_kt_cap", 0) < M:
-            self._kt_cap = M
-            sizes = [lib.vlb_lora_keep_tiles_bytes(M, self.in_dims[ts[0]], len(ts)) for _, ts in GROUPS]
-            self._kt_off = [sum(sizes[:i]) for i in range(len(sizes))]
-            self._kt_layer = (sum(sizes) + 63) // 64 * 64
-            self._kt_buf = torch.empty(len(self.layers) * self._kt_layer, dtype=torch.uint8, device=self.dev)
-            self._kt_rows = M
-        if M != self._kt_rows:          # the tile geometry (group stride) follows the row count of the CALL: re-carve, no realloc
-            sizes = [lib.vlb_lora_keep_tiles_bytes(M, self.in_dims[ts[0]], len(ts)) for _, ts in GROUPS]
-            self._kt_off = [sum(sizes[:i]) for i in range(len(sizes))]
-            self._kt_rows = M
-        return self._kt_buf[li * self._kt_layer + self._kt_off[gi]:]
-
-    def _lora_t(self, x, blk, seeds, slot=None, p=None, keep=False):
-        """t = s/(1-p) * keep(x) . A^T for every projection of the group (the fused GEMM's second A operand).
-        ``keep``: also store the dropout keep bits for this step's backward (training forward only)."""
+    def _lora_t(self, x, blk, seeds, slot=None, p=None):
+        """t = s/(1-p) * keep(x) . A^T for every projection of the group (the fused GEMM's second A operand)."""
         t = self._t_buffer(*slot, x.shape[0]) if slot is not None else torch.zeros(x.shape[0], blk["Rpad"], dtype=BF16, device=self.dev)
         p = self.p if p is None else p
         gs = self._group_seeds(seeds, len(blk["targets"])) if p > 0 else None
-        kt = self._keep_tiles(*slot, x.shape[0]) if keep and slot is not None and p > 0 else None
         for r0 in range(0, blk["R"], 48):                       # the skinny kernel takes up to three 16-rank blocks per launch
             n = min(48, blk["R"] - r0)
-            lora_down(x, blk["A"][r0:r0 + n], n, self.scale, p, None if gs is None else gs[r0 // 16:(r0 + n) // 16], t[:, r0:], kt)
+            lora_down(x, blk["A"][r0:r0 + n], n, self.scale, p, None if gs is None else gs[r0 // 16:(r0 + n) // 16], t[:, r0:])
         return t
 
-    def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None, keep=False):
-        t = self._lora_t(x, blk, seeds, slot, p, keep)
+    def _adapted(self, x, W, blk, seeds, residual=None, slot=None, p=None):
+        t = self._lora_t(x, blk, seeds, slot, p)
         return ops.gemm(x, W, residual=residual, a2=t, w2=blk["Bpad"]), t
 
     def _adapted_mlp_in(self, x, lw, blk, seeds, slot, p=None, save=True):
         """Adapted gate/up projection + SwiGLU: returns (silu(gate)*up, [gate | up] or None, t)."""
         if self.gu_il:
-            t = self._lora_t(x, blk, seeds, slot, p, keep=save)
+            t = self._lora_t(x, blk, seeds, slot, p)
             if save:
                 hh, gu = ops.gemm_swiglu_save(x, lw["wgu_il"], a2=t, w2_il=blk["Bpad"])
                 return hh, gu, t
             return ops.gemm(x, lw["wgu_il"], act=ops.ACT_SWIGLU_PAIR, a2=t, w2=blk["Bpad"]), None, t
-        gu, t = self._adapted(x, lw["wgu"], blk, seeds, slot=slot, p=p, keep=save)
+        gu, t = self._adapted(x, lw["wgu"], blk, seeds, slot=slot, p=p)
         return ops.swiglu(gu), gu, t
 
     def forward(self, backbone, vision_f32, ids, layout=None, train=True):
@@ -339,15 +314,15 @@ class LoraState:
             lw = backbone.layer_weights(li)
             sd = [self._seed(li, k) for k in range(7)]
             h1 = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
-            qkv, t_qkv = self._adapted(h1, lw["wqkv"], lay["qkv"], sd[0:3], slot=(li, 0), keep=True)
+            qkv, t_qkv = self._adapted(h1, lw["wqkv"], lay["qkv"], sd[0:3], slot=(li, 0))
             ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
             a, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads,
                                        g.head_dim, True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True,
                                        layout=layout)
-            x2, t_o = self._adapted(a, lw["wo"], lay["o"], sd[3:4], residual=x, slot=(li, 1), keep=True)
+            x2, t_o = self._adapted(a, lw["wo"], lay["o"], sd[3:4], residual=x, slot=(li, 1))
             h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
             hh, gu, t_gu = self._adapted_mlp_in(h2, lw, lay["gu"], sd[4:6], (li, 2))
-            x3, t_d = self._adapted(hh, lw["wdown"], lay["down"], sd[6:7], residual=x2, slot=(li, 3), keep=True)
+            x3, t_d = self._adapted(hh, lw["wdown"], lay["down"], sd[6:7], residual=x2, slot=(li, 3))
             self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh, t_qkv=t_qkv, t_o=t_o,
                                    t_gu=t_gu, t_d=t_d, seeds=sd))
             x = x3
@@ -402,12 +377,10 @@ class LoraState:
             col += n
         # dA[r,in] = sum_m u[m,r] keep_g(x[m,in])/(1-p) for every projection of the group in one pass over x (48 ranks per launch)
         gs = self._group_seeds(seeds, len(lay["targets"])) if self.p > 0 else None
-        gi = [g for g, _ in GROUPS].index(gname)
-        kt = self._keep_tiles(li, gi, x_in.shape[0]) if self.p > 0 else None       # the bits this step's forward stored for x_in
         for r0 in range(0, lay["R"], 48):
             n = min(48, lay["R"] - r0)
             wgrad_skinny(u[:, r0:], x_in, self.grad_A[li][gname][r0:r0 + n], ws["wg"], n, p=self.p,
-                         seeds=None if gs is None else gs[r0 // 16:(r0 + n) // 16], keep_tiles=kt)
+                         seeds=None if gs is None else gs[r0 // 16:(r0 + n) // 16])
         if not need_dx:
             return None
         if self.p == 0.0:
@@ -422,7 +395,7 @@ class LoraState:
             dx = ops.gemm(dy, W_t)
             for r0 in range(0, lay["R"], 48):
                 n = min(48, lay["R"] - r0)
-                lora_dx_masked(u[:, r0:], lay["At"][:, r0:], dx, n, self.p, gs[r0 // 16:(r0 + n) // 16], keep_tiles=kt)
+                lora_dx_masked(u[:, r0:], lay["At"][:, r0:], dx, n, self.p, gs[r0 // 16:(r0 + n) // 16])
         return dx if swiglu_gu is None else ops.swiglu_bwd(swiglu_gu, dx)
 
     def backward(self, backbone, dhidden):
