@@ -160,24 +160,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[s][r] = 0.f;
-      // K row fragments are read ONE k-step ahead of the MFMAs that use them (the compiler left to itself waits
-      // lgkmcnt(0) in front of every MFMA pair: an exposed LDS latency per k-step); sched_group_barrier pins the
-      // order [2 reads of step ks+1][2 MFMAs of step ks], which makes the waits counted (lgkmcnt(2)).
-      bf16x8 kfc[2], kfn[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) kfc[s] = *reinterpret_cast<const bf16x8*>(kb + k_rd[0] + 32 * s * ROWB);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s) kfn[s] = *reinterpret_cast<const bf16x8*>(kb + k_rd[ks + 1] + 32 * s * ROWB);
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + k_rd[ks] + 32 * s * ROWB);
+          st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[s], 0, 0, 0);
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfc[s], qf[ks], st[s], 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) kfc[s] = kfn[s];
-        if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
       // ---- masks: key validity (padding + sequence end) as one 64-bit word, causal on diagonal tiles.
       // The masked path is a separate wave-uniform branch (most tiles are full and skip it entirely).
@@ -759,23 +748,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p, bf
       f32x16 sacc, pacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-      // fragments one k-step ahead of their MFMAs, order pinned [3 reads of ks+1][2 MFMAs of ks] (see the forward kernel)
-      auto rd3 = [&](int ks, bf16x8 (&f)[3]) {
-        f[0] = *reinterpret_cast<const bf16x8*>(qt + q_base + (((2 * ks) ^ q_x) << 4));
-        f[1] = *reinterpret_cast<const bf16x8*>(dot + q_base + (((2 * ks) ^ q_x) << 4));
-        f[2] = *reinterpret_cast<const bf16x8*>(smem + V_OFF + v_base + (((2 * ks) ^ v_x) << 4));
-      };
-      bf16x8 fc[3], fn[3];
-      rd3(0, fc);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) rd3(ks + 1, fn);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[0], kf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[1], fc[2], pacc, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) fc[i] = fn[i];
-        if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + q_base + (((2 * ks) ^ q_x) << 4));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sacc, 0, 0, 0);
+        const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dot + q_base + (((2 * ks) ^ q_x) << 4));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + V_OFF + v_base + (((2 * ks) ^ v_x) << 4));
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf, pacc, 0, 0, 0);
       }
       bf16x8 pb[2], dsb[2];
 #pragma unroll
@@ -968,28 +947,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnDqArgs p) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[s][r] = 0.f; dp[s][r] = 0.f; }
-      // K / V row fragments one k-step ahead of their MFMAs, order pinned [4 reads of ks+1][4 MFMAs of ks]
-      auto rd4 = [&](int ks, bf16x8 (&f)[4]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f[2 * s] = *reinterpret_cast<const bf16x8*>(kb + row_rd[ks] + 32 * s * ROWB);
-          f[2 * s + 1] = *reinterpret_cast<const bf16x8*>(vb + row_rd[ks] + 32 * s * ROWB);
-        }
-      };
-      bf16x8 fc[4], fn[4];
-      rd4(0, fc);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) rd4(ks + 1, fn);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[2 * s], qf[ks], st[s], 0, 0, 0);
-          dp[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[2 * s + 1], dof[ks], dp[s], 0, 0, 0);
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row_rd[ks] + 32 * s * ROWB);
+          st[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[s], 0, 0, 0);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + row_rd[ks] + 32 * s * ROWB);
+          dp[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[s], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fc[i] = fn[i];
-        if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       unsigned long long kvalid;
       {
