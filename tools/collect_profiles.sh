@@ -2,7 +2,7 @@
 # Re-collects every round-3 file under profiles/ on a one-GPU MI355X box (run from the repo root: `gpurun -- 'bash tools/collect_profiles.sh'`).
 # Kernel traces and PMC passes are separate rocprofv3 runs (counters never share a run with a trace); raw traces are deleted, the
 # summaries written by tools/profile_tables.py land in profiles/ and are copied to gpurun_out/pf/out/ so that they travel back.
-set -e
+set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pf && mkdir -p gpurun_out/pf
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/lora -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/pf/lora.log 2>&1
@@ -23,4 +23,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 python3 tools/profile_tables.py stats gpurun_out/pf/full 4 r03_bench_full7b > gpurun_out/pf/full_tables.log 2>&1
 python3 tools/bench_hbm_kernels.py > profiles/r03_hbm_bound_kernels.txt 2> gpurun_out/pf/hbm.err
 mkdir -p gpurun_out/pf/out && cp profiles/r03_* profiles/gateup_traffic.json gpurun_out/pf/out/
+for f in gpurun_out/pf/*_tables.log; do echo "== $f"; tail -n 4 $f; done
+grep -h '"metric"' gpurun_out/pf/*.log || true
 find gpurun_out/pf -name "*kernel_trace.csv" -delete; find gpurun_out/pf -name "*counter_collection.csv" -delete; find gpurun_out/pf -name "*.db" -delete
