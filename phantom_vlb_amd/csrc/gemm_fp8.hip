@@ -220,9 +220,245 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
   }
 }
 
+// ---------------------------------------------------------------- pipelined variant (round 3)
+// Same tile, LDS image and operand layout as gemm_mxfp8_kernel, but no fragment-read phase in front of the MFMAs: the 64
+// MFMAs of a K-tile run as two blocks of NT groups, group j = W fragment j against activation rows 0..3 (block 1) or 4..7
+// (block 2), and every ds_read is issued under MFMAs that do not need it:
+//   block 1 of tile kt: reads activation fragments 4..7 of tile kt; after barrier S (every wave holds all of W(kt)) the W
+//                       image of this stage is refilled with W(kt+2) by LDS-DMA
+//   barrier M:          every wave holds all of tile kt, and tile kt+1 has landed (counted vmcnt: only W(kt+2) may fly)
+//   block 2 of tile kt: LDS-DMA of A(kt+2) into this stage's A image; reads of tile kt+1 from the other stage: activation
+//                       fragments 0..3 up front (their registers died with block 1), W fragment j IN PLACE right behind the
+//                       last MFMA group that uses it
+// so the register file holds one set of fragments (8 + NT), the DMA pieces are spread over both blocks, and each piece has
+// one to two blocks (1000-3000 matrix cycles) to land.  Scale bytes are fetched with ds_read_u8 (byte g of the row's word).
+template <int NT, int S_AT>
+__global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8Launch L) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = 256 * FROW, WROWS = 32 * NT, W_BYTES = WROWS * FROW;
+  constexpr int SA_OFF = A_BYTES + W_BYTES, SW_OFF = SA_OFF + 256 * 4;
+  constexpr int STAGE = SW_OFF + 256 * 4;
+  constexpr int NW = NT + 1, NA = 9;                         // LDS-DMA pieces per wave per K-tile: W image + scale words, A image + scale words
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int w;
+  {
+    const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int T = n >> 8, tr = idx >> 5;
+    if (tr < T) {
+      w = (tr << 8) + (xcd << 5) + (idx & 31);
+    } else {
+      const int base = T << 8, nn = n - base, q = nn >> 3, r = nn & 7;
+      w = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (idx - (T << 5));
+    }
+  }
+  const int t = L.tile0 + w / L.split_n, half = w % L.split_n;
+  const int band = t / (8 * p.tiles_m), c0 = band * 8, within = t - band * 8 * p.tiles_m;
+  const int band_cols = min(8, p.tiles_n - c0);
+  const int tm = within / band_cols, tn = c0 + within % band_cols;
+  const int m0 = tm * 256, n0 = tn * 256 + half * 128;
+  const int nk = p.K / FBK;
+
+  // LDS-DMA sources = uniform base (advanced 128 B per K-tile) + one 32-bit byte offset per piece (host checks the extents)
+  uint32_t offA[8], offW[NT];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = wave * 64 + j * 8 + (lane >> 3), s = lane & 7;
+    offA[j] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)p.lda + (uint32_t)((s ^ ((r >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = wave * 8 * NT + j * 8 + (lane >> 3), s = lane & 7;
+    offW[j] = (uint32_t)(n0 + r) * (uint32_t)p.ldw + (uint32_t)((s ^ ((r >> 1) & 7)) * 16);
+  }
+  const uint32_t offSA = (uint32_t)min(m0 + wave * 64 + lane, p.M - 1) * (uint32_t)p.ldsa;
+  const uint32_t offSW = (uint32_t)(n0 + (wave * 64 + lane) % WROWS) * (uint32_t)p.ldsw;
+  const char* const baseA = reinterpret_cast<const char*>(p.A); const char* const baseW = reinterpret_cast<const char*>(p.W);
+  const char* const baseSA = reinterpret_cast<const char*>(p.sA); const char* const baseSW = reinterpret_cast<const char*>(p.sW);
+  auto dmaW = [&](int st, int kt, int pc) {                  // piece pc of W(kt): 0..NT-1 image, NT scale words
+    char* base = smem + st * STAGE;
+    if (pc < NT) glds16f(baseW + (int64_t)kt * FBK + offW[pc], base + A_BYTES + (wave * NT + pc) * 1024);
+    else glds4f(baseSW + kt * 4 + offSW, base + SW_OFF + wave * 256);
+  };
+  auto dmaA = [&](int st, int kt, int pc) {                  // piece pc of A(kt): 0..7 image, 8 scale words
+    char* base = smem + st * STAGE;
+    if (pc < 8) glds16f(baseA + (int64_t)kt * FBK + offA[pc], base + (wave * 8 + pc) * 1024);
+    else glds4f(baseSA + kt * 4 + offSA, base + SA_OFF + wave * 256);
+  };
+  const int fr = lane & 15, g = lane >> 4;
+  f32x4 acc[NT][8];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8 wf[NT], af[8];
+  int swb[NT], sab[8];
+  auto readW = [&](const char* sb, int j) {
+    const int r = wn * 16 * NT + j * 16 + fr;
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, g));
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, 4 + g));
+    wf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    swb[j] = *reinterpret_cast<const uint8_t*>(sb + SW_OFF + r * 4 + g);
+  };
+  auto readA = [&](const char* sb, int i) {
+    const int r = wm * 128 + i * 16 + fr;
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + f_off(r, g));
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + f_off(r, 4 + g));
+    af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    sab[i] = *reinterpret_cast<const uint8_t*>(sb + SA_OFF + r * 4 + g);
+  };
+#define VLB_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define VLB_FENCE() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+  for (int pc = 0; pc < NW; ++pc) dmaW(0, 0, pc);
+#pragma unroll
+  for (int pc = 0; pc < NA; ++pc) dmaA(0, 0, pc);
+  if (nk > 1) {
+#pragma unroll
+    for (int pc = 0; pc < NW; ++pc) dmaW(1, 1, pc);
+#pragma unroll
+    for (int pc = 0; pc < NA; ++pc) dmaA(1, 1, pc);
+    VLB_VMCNT(NW + NA);
+  } else {
+    VLB_VMCNT(0);
+  }
+  VLB_FENCE(); __builtin_amdgcn_s_barrier(); VLB_FENCE();
+#pragma unroll
+  for (int j = 0; j < NT - 1; ++j) readW(smem, j);           // (fragment NT-1 is fetched at the top of every tile)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) readA(smem, i);
+  __builtin_amdgcn_s_waitcnt(0xc07f);                        // so that no compiler-inserted full wait lands at the loop header
+  VLB_FENCE();
+
+  // MORE: a tile kt+1 exists (its fragments are fetched in block 2); LOAD2: a tile kt+2 exists (it is DMAed into this stage)
+  auto tile = [&](int kt, auto more_c, auto load2_c) {
+    constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
+    const int st = kt & 1;
+    const char* sb = smem + st * STAGE;
+    const char* sn = smem + (st ^ 1) * STAGE;
+    // ---------------- block 1: W fragment j x activation rows 0..3 || reads of rows 4..7 || DMA of W(kt+2)
+    readW(sb, NT - 1);                                       // the one W fragment block 2 of the previous tile could not refresh in time
+#pragma unroll
+    for (int i = 4; i < 8; ++i) readA(sb, i);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (LOAD2) {
+        if (j == S_AT) {                                     // S: every wave holds W(kt) - this stage's W image is free
+          __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0), as an instruction the compiler's own wait insertion accounts for
+          VLB_FENCE(); __builtin_amdgcn_s_barrier(); VLB_FENCE();
+        }
+        if (j >= S_AT) {
+#pragma unroll
+          for (int pc = 0; pc < NW; ++pc)
+            if (pc * (NT - S_AT) / NW == j - S_AT) dmaW(st, kt + 2, pc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sc = swb[j] | (sab[i] << 8);
+        acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
+      }
+      VLB_FENCE();
+    }
+    if constexpr (MORE) {
+      // M: every wave holds all of tile kt (its A image is free); tile kt+1 has landed - only W(kt+2)'s pieces may still fly
+      __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0), as an instruction the compiler's own wait insertion accounts for
+      if constexpr (LOAD2) VLB_VMCNT(NW); else VLB_VMCNT(0);
+      VLB_FENCE(); __builtin_amdgcn_s_barrier(); VLB_FENCE();
+    }
+    // ---------------- block 2: W fragment j x activation rows 4..7 || DMA of A(kt+2) || reads of tile kt+1
+    if constexpr (MORE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) readA(sn, i);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (LOAD2) {
+#pragma unroll
+        for (int pc = 0; pc < NA; ++pc)
+          if (pc * NT / NA == j) dmaA(st, kt + 2, pc);
+      }
+      if constexpr (MORE) { if (j >= 1) readW(sn, j - 1); }  // in place: fragment j-1 died with the previous group
+#pragma unroll
+      for (int i = 4; i < 8; ++i) {
+        const int sc = swb[j] | (sab[i] << 8);
+        acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
+      }
+      VLB_FENCE();
+    }
+  };
+  {
+    using T_ = std::true_type; using F_ = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) tile(kt, T_{}, T_{});
+    if (kt + 1 < nk) { tile(kt, T_{}, F_{}); ++kt; }
+    tile(kt, F_{}, F_{});
+  }
+#undef VLB_VMCNT
+#undef VLB_FENCE
+  auto value = [&](const f32x4& a, int m, int n) {
+    f32x4 v = a;
+    if (p.residual) {
+      const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+    return o;
+  };
+  const bool wide = ((uintptr_t)p.C % 16) == 0 && p.ldc % 8 == 0;
+  if (wide) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
+        store_pair16(p.C + (int64_t)m * p.ldc, n, value(acc[j][i], m, n), value(acc[j + 1][i], m, n + 16), g);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
+      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = value(acc[j][i], m, n);
+    }
+  }
+}
+
+#ifdef VLB_TOOLS
+int g_fp8_variant = 1;              // tools: 0 = read-phase kernel (rounds 1-2), 1 = pipelined kernel
+#else
+constexpr int g_fp8_variant = 1;
+#endif
+
 template <int NT>
 int launch_fp8(const Fp8Args& a, Fp8Launch L, int grid, hipStream_t st) {
   constexpr int LDS = 2 * (256 * FROW + 32 * NT * FROW + 2 * 256 * 4);
+#ifdef VLB_TOOLS
+  if (g_fp8_variant == 2 || g_fp8_variant == 3) {            // tools: barrier S in front of MFMA group 2 / 0 instead of 1
+    auto k = g_fp8_variant == 2 ? &gemm_mxfp8_pipe_kernel<NT, 2> : &gemm_mxfp8_pipe_kernel<NT, 0>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return VLB_ERR_LAUNCH;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, a, L);
+    VLB_LAUNCH_CHECK();
+    return VLB_OK;
+  }
+#endif
+  if (g_fp8_variant == 1) {
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_pipe_kernel<NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr1 != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr1)); return VLB_ERR_LAUNCH; }
+    hipLaunchKernelGGL((gemm_mxfp8_pipe_kernel<NT, 1>), dim3(grid), dim3(256), LDS, st, a, L);
+    VLB_LAUNCH_CHECK();
+    return VLB_OK;
+  }
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
   hipLaunchKernelGGL((gemm_mxfp8_kernel<NT>), dim3(grid), dim3(256), LDS, st, a, L);
@@ -340,6 +576,7 @@ __global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf1
 }  // namespace
 
 #ifdef VLB_TOOLS
+extern "C" void vlb_gemm_mxfp8_set_variant(int v) { g_fp8_variant = v; }
 // tools build only: ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-given per-lane registers (layout experiments)
 namespace {
 template <int OA, int OB>
@@ -396,6 +633,7 @@ extern "C" int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa,
   VLB_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq) % 16) == 0 && ((uintptr_t)C % 8) == 0 && (((uintptr_t)sA | (uintptr_t)sW) % 4) == 0,
               "gemm_mxfp8: misaligned operand");
   if (residual) VLB_REQUIRE(ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0, "gemm_mxfp8: bad residual");
+  VLB_REQUIRE((int64_t)M * lda < (1ll << 32) && (int64_t)N * ldw < (1ll << 32), "gemm_mxfp8: operands above 4 GiB are not supported (32-bit staging offsets)");
   Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
             M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + 255) / 256, N / 256};
   // One workgroup per CU: the GEMM runs in rounds of 256 tiles.  When the last round is at most 5/8 full its tiles
