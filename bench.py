@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 / MX-fp8 MFMA (same source; the headline figures with 2:1 sparsity are never used)
 
 
 def gateup_traffic(shape):
@@ -264,17 +265,18 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches, (pM, pN, pK) = probe.result()
-    traffic, traffic_src = gateup_traffic((pM, pN, pK))
+    traffic, traffic_src = gateup_traffic((pM, pN, pK)) if not a.fp8 else (None, None)      # the recorded collections are of the bf16 calls
     if rank == 0:
         clips = world * B * a.steps
         value = clips / dt
         flops_launch = 2.0 * pM * pN * pK
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12 if kern_ms else 0.0
+        peak_tf = PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS
         out = {
             "metric": "clips/sec fine-tune VideoLLaMA2-7B+LoRA->2k-voxel head, 1/2/4/8 MI355X",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "mxfp8 (e4m3 + E8M0 block scales) decoder GEMMs, bf16 elsewhere" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": {"frozen": "configs[1]: VideoLLaMA2-7B frozen backbone + linear 2k-voxel head, bf16",
                                     "lora": "configs[2]: VideoLLaMA2-7B + LoRA r=16 + 2k-voxel head, bf16",
                                     "full": f"configs[4] model side: VideoLLaMA2-7B full-parameter fine-tune (all but the vision tower), "
@@ -296,15 +298,18 @@ def main():
                        # executed FLOPs: the per-clip figure scaled by the rows actually run (conservative: the vision tower is not reduced)
                        "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense, 1),
                        "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + the split-K launches of its partial last wave "
+            "roofline": {"bound": "mfma", "kernel": (f"gemm_mxfp8 kernel (256x256x128 tile, 4 waves x 128x128, v_mfma_scale_f32_16x16x128_f8f6f4) + the re-cut launch of its partial "
+                                                     f"last round on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_mxfp8 call; peak = dense fp8 MFMA" if a.fp8 else
+                                                     "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + the split-K launches of its partial last wave "
                          f"on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per "
                          + ("vlb_gemm_swiglu_save call (epilogue: + LoRA pair, SwiGLU, saved pre-activations; FLOPs counted: the base GEMM only)" if lora
-                            else "vlb_gemm_bf16 call"), "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                            else "vlb_gemm_bf16 call")), "achieved": round(achieved, 1), "peak": peak_tf,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak_tf, 4),
                          "traffic": traffic,
                          "traffic_note": (f"L2->fabric bytes per call from rocprofv3 PMC passes ({traffic_src}, via profiles/gateup_traffic.json); "
                                           if traffic is not None else "no PMC collection on record for this shape (profiles/gateup_traffic.json); ")
                          + (f"algorithmic {2.0 * (pM * (pK + 64) + pN * (pK + 64)) + 2.0 * pM * pN + 1.0 * pM * pN:.3e} (A | t, W | B, saved [gate|up] [M,N] and silu(gate)*up [M,N/2], bf16)" if lora else
+                            f"algorithmic {(pM * pK + pN * pK) * (1 + 1 / 32) + 2.0 * pM * pN:.3e} (e4m3 A + W with their E8M0 scales, C [M,N] bf16)" if a.fp8 else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},

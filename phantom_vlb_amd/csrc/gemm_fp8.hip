@@ -38,6 +38,8 @@ __device__ __forceinline__ void glds4f(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 4, 0, 0);
 }
 
+struct Fp8Launch { int tile0, split_n; };       // first tile id of this launch; 1 = whole tiles, 2 = column halves
+#ifdef VLB_TOOLS          // the read-phase kernel of rounds 1-2, kept in the tools build for A/B (tools/ab_fp8_variants.py)
 // 256 threads = 2(M) x 2(N) waves, one per SIMD with the full 512-register budget; wave block 128 x 128 = 64
 // accumulator tiles.  Per K-tile (128 bytes of K per row) a wave reads all its fragments (32 ds_read_b128) and scale
 // words into registers, the workgroup passes a barrier, and the stage just read is immediately refilled with tile
@@ -47,7 +49,6 @@ __device__ __forceinline__ void glds4f(const void* g, void* l) {
 // drain the DMA queue on.
 // NT = 8: 256 x 256 tile (wave block 128 x 128).  NT = 4: 256 x 128 tile (wave block 128 x 64) - the partial last
 // wave of tiles of a GEMM is re-cut into these halves so its work spreads over twice as many CUs.
-struct Fp8Launch { int tile0, split_n; };       // first tile id of this launch; 1 = whole tiles, 2 = column halves
 
 template <int NT>
 __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch L) {
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------- pipelined variant (round 3)
 // Same tile, LDS image and operand layout as gemm_mxfp8_kernel, but no fragment-read phase in front of the MFMAs: the 64
@@ -396,42 +398,44 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
   }
 #undef VLB_VMCNT
 #undef VLB_FENCE
-  auto value = [&](const f32x4& a, int m, int n) {
-    f32x4 v = a;
-    if (p.residual) {
-      const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.residual + (int64_t)m * p.ldr + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-    }
+  // ---- epilogue: lane holds, for tile (j, i): output row m = .. + fr, columns n = .. + 4g + {0,1,2,3}.  One fully
+  // unrolled loop nest per (residual?, 16-byte rows?) case, chosen once (compact instruction stream, no per-fragment branch).
+  auto cvt = [](const f32x4& v) {
     bf16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
     return o;
   };
-  const bool wide = ((uintptr_t)p.C % 16) == 0 && p.ldc % 8 == 0;
-  if (wide) {
+  auto rows = [&](auto res_c, auto wide_c) {
+    constexpr bool RES = decltype(res_c)::value, WIDE = decltype(wide_c)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wm * 128 + i * 16 + fr;
       if (m >= p.M) continue;
+      bf16* crow = p.C + (int64_t)m * p.ldc;
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
         const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
-        store_pair16(p.C + (int64_t)m * p.ldc, n, value(acc[j][i], m, n), value(acc[j + 1][i], m, n + 16), g);
+        f32x4 va = acc[j][i], vb = acc[j + 1][i];
+        if constexpr (RES) {
+          const bf16* rp = p.residual + (int64_t)m * p.ldr + n;
+          const bf16x4 ra = *reinterpret_cast<const bf16x4*>(rp), rb = *reinterpret_cast<const bf16x4*>(rp + 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] += (float)ra[e]; vb[e] += (float)rb[e]; }
+        }
+        if constexpr (WIDE) {
+          store_pair16(crow, n, cvt(va), cvt(vb), g);
+        } else {
+          *reinterpret_cast<bf16x4*>(crow + n) = cvt(va);
+          *reinterpret_cast<bf16x4*>(crow + n + 16) = cvt(vb);
+        }
       }
     }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + fr;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * 16 * NT + j * 16 + 4 * g;
-      *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + n) = value(acc[j][i], m, n);
-    }
-  }
+  };
+  using ET_ = std::true_type; using EF_ = std::false_type;
+  const bool wide = ((uintptr_t)p.C % 16) == 0 && p.ldc % 8 == 0;
+  if (wide) { if (p.residual) rows(ET_{}, ET_{}); else rows(EF_{}, ET_{}); }
+  else { if (p.residual) rows(ET_{}, EF_{}); else rows(EF_{}, EF_{}); }
 }
 
 #ifdef VLB_TOOLS
@@ -459,11 +463,15 @@ int launch_fp8(const Fp8Args& a, Fp8Launch L, int grid, hipStream_t st) {
     VLB_LAUNCH_CHECK();
     return VLB_OK;
   }
+#ifdef VLB_TOOLS
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
   hipLaunchKernelGGL((gemm_mxfp8_kernel<NT>), dim3(grid), dim3(256), LDS, st, a, L);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
+#else
+  return VLB_ERR_LAUNCH;
+#endif
 }
 
 // ---------------------------------------------------------------- bf16 -> MX fp8 (e4m3 + E8M0 block scales)
