@@ -714,7 +714,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   constexpr int A_LD = BM / 32, B_LD = BN / 32;       // LDS-DMA instructions per thread per tile (32 rows each)
   constexpr int ND = A_LD + B_LD;
   static_assert((NT == 8 || NT == 4) && (MT == 8 || MT == 6), "wave block 128|96 rows x 128|64 columns");
-  static_assert(ND <= 2 * NG && (NT - 1) < NG && (2 * (MT - 2) + 2) * NT / 8 < NG, "schedule does not fit the block");
+  constexpr bool ROWSPLIT = (ABL & 64) != 0;            // the K loop that splits a K-tile's MFMAs by output rows instead of by k-step (below)
+  static_assert(ROWSPLIT || (ND <= 2 * NG && (NT - 1) < NG && (2 * (MT - 2) + 2) * NT / 8 < NG), "schedule does not fit the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int m0, n0;
@@ -815,16 +816,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // is loaded right behind it.  Only af[7] dies too late (it would have to be read after the barrier that
   // releases its buffer), so it alone has a second slot (a7[2]).
   bf16x8 wf[2][NT], af[MT - 1], a7[2];
+  // Row-split loop (ROWSPLIT): one set of fragments for BOTH k-steps, wr[ks][j] / ar[ks][i]; see tile_r below.
+  constexpr int HM = MT / 2;
+  bf16x8 wr[2][NT], ar[2][MT];
+  if constexpr (!ROWSPLIT) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) wf[0][j] = frag(smem, b_off[0], j);
+    for (int j = 0; j < NT; ++j) wf[0][j] = frag(smem, b_off[0], j);
 #pragma unroll
-  for (int i = 0; i < MT - 1; ++i) af[i] = frag(smem, a_off[0], i);
-  a7[0] = frag(smem, a_off[0], MT - 1);
+    for (int i = 0; i < MT - 1; ++i) af[i] = frag(smem, a_off[0], i);
+    a7[0] = frag(smem, a_off[0], MT - 1);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NT - 1; ++j) wr[ks][j] = frag(smem, b_off[ks], j);      // (fragment NT-1 is fetched at the top of every tile)
+#pragma unroll
+      for (int i = 0; i < HM; ++i) ar[ks][i] = frag(smem, a_off[ks], i);
+    }
+  }
   __builtin_amdgcn_s_waitcnt(0xc07f);        // so that no compiler-inserted wait lands inside the loop
   W4_FENCE();
 
   // one K-tile; MORE: a tile kt+1 exists (fetch its first fragments), LOAD2: tile kt+2 exists (LDS-DMA it)
-  auto tile = [&](int kt, auto more_c, auto load2_c) {
+  auto tile_k = [&](int kt, auto more_c, auto load2_c) {
     constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
     const char* sb = smem + (kt & 1) * STAGE;
     const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
@@ -874,6 +888,84 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     asm volatile("s_nop 15" ::: "memory");
     W4_FENCE();
   };
+  // Row-split K-tile (the MX-fp8 kernel's schedule, gemm_fp8.hip): the tile's MFMAs run as two blocks of NT groups, group j =
+  // W fragment j (both k-steps) against row tiles 0..HM-1 (block 1) or HM..MT-1 (block 2).  W fragments are refreshed in place
+  // one group behind their last use in block 2, the row halves alternate, so ONE set of fragments serves and - unlike the
+  // k-step split, whose stage only frees up at the middle barrier - the W image is free early in block 1 (barrier S): the
+  // LDS-DMA pieces of tile kt+2 are spread over BOTH blocks (W in block 1, A in block 2), half as dense among the MFMAs.
+  auto tile_r = [&](int kt, auto more_c, auto load2_c) {
+    constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
+    constexpr int S_AT = 1;
+    const char* sb = smem + (kt & 1) * STAGE;
+    const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wr[ks][NT - 1] = frag(sb, b_off[ks], NT - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = HM; i < MT; ++i) ar[ks][i] = frag(sb, a_off[ks], i);
+    // ---------------- block 1: rows 0..HM-1 || DMA of W(kt+2)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (LOAD2) {
+        if (j == S_AT) {                      // S: every wave holds all W fragments of tile kt - this stage's W image is free
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          W4_BARRIER();
+          select(kt + 2);
+        }
+        if (j >= S_AT) {
+#pragma unroll
+          for (int pc = 0; pc < B_LD; ++pc)
+            if (pc * (NT - S_AT) / B_LD == j - S_AT) dma(kt & 1, A_LD + pc);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < HM; ++i) mfma_tied(acc[i][j], wr[ks][j], ar[ks][i]);
+      W4_FENCE();
+    }
+    if constexpr (MORE) {
+      // M: every wave holds all of tile kt (the A image is free too); tile kt+1 has landed - only W(kt+2) may still fly
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if constexpr (LOAD2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_LD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      W4_BARRIER();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < HM; ++i) ar[ks][i] = frag(sn, a_off[ks], i);
+    }
+    // ---------------- block 2: rows HM..MT-1 || DMA of A(kt+2) || W fragments of tile kt+1 in place
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if constexpr (LOAD2) {
+#pragma unroll
+        for (int pc = 0; pc < A_LD; ++pc)
+          if (pc * NT / A_LD == j) dma(kt & 1, pc);
+      }
+      if constexpr (MORE) {
+        if (j >= 1) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) wr[ks][j - 1] = frag(sn, b_off[ks], j - 1);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = HM; i < MT; ++i) mfma_tied(acc[i][j], wr[ks][j], ar[ks][i]);
+      W4_FENCE();
+    }
+    asm volatile("s_nop 15" ::: "memory");
+    W4_FENCE();
+  };
+#ifdef VLB_TOOLS
+  auto tile = [&](int kt, auto more_c, auto load2_c) {
+    if constexpr (ROWSPLIT) tile_r(kt, more_c, load2_c); else tile_k(kt, more_c, load2_c);
+  };
+#else
+  auto& tile = tile_k;                   // product build: the k-step loop, called directly (tile_r is never instantiated)
+#endif
   using T_ = std::true_type; using F_ = std::false_type;
   int kt = 0;
   if constexpr (MASKED) {
@@ -1008,6 +1100,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
 #undef W4_REDUCE_EPILOGUE
 }
 
+#ifdef VLB_TOOLS
+int g_w4_rowsplit = 0;              // tools: 1 = every four-wave launch uses the row-split K loop (ABL bit 6)
+#endif
 template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
@@ -1018,6 +1113,17 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return VLB_ERR_LAUNCH;
   }
+#ifdef VLB_TOOLS
+  if constexpr (ABL == 0) {
+    if (g_w4_rowsplit) {                     // tools A/B: the row-split K loop
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, 64, MT, MASKED, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return VLB_ERR_LAUNCH;
+      hipLaunchKernelGGL((gemm_w4_kernel<NT, 64, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
+      VLB_LAUNCH_CHECK();
+      return VLB_OK;
+    }
+  }
+#endif
   hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
@@ -1460,6 +1566,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
 #ifdef VLB_TOOLS
 // tuning hooks, libvlb_tools.so only: kernel variant / forced tile
 extern "C" void vlb_gemm_set_stagger(int ticks) { g_stagger = ticks; }
+extern "C" void vlb_gemm_set_rowsplit(int on) { g_w4_rowsplit = on; }
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;
