@@ -42,6 +42,7 @@ struct GemmArgs {
   bf16* aux; int ldaux;
   int stagger;              // tools build only (timing experiment): odd workgroups of the first round start this many 10-ns ticks late
   int wide;                 // C (and aux) rows 16-byte aligned: required by the four-wave kernels, which store 16 bytes per lane (store_pair16)
+  int persist_iters;        // tools build only (persistent experiment): output tiles per workgroup, grid = 256
 };
 
 // blockIdx -> (m0, n0).  The order is defined on the full parent grid, so a GEMM can be cut into several launches (full
@@ -718,8 +719,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   static_assert(ROWSPLIT || (ND <= 2 * NG && (NT - 1) < NG && (2 * (MT - 2) + 2) * NT / 8 < NG), "schedule does not fit the block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  constexpr bool PERSIST = (ABL & 128) != 0;             // tools: one workgroup per CU streams over persist_iters output tiles (below)
+  static_assert(!PERSIST || (!MASKED && !SPLITK && !ROWSPLIT), "persistent stream: plain launches only");
   int m0, n0;
-  const int ksplit = map_tile(p, BM, BN, m0, n0);
+  int ksplit = 0;
+  // persistent stream: work item `it` of workgroup b is tile id it*256 + (b&7)*32 + (b>>3) - the tile a launch of
+  // persist_iters*256 workgroups hands to the same CU slot in its round `it` (tile order bit 1)
+  auto persist_coords = [&](int it, int& pm0, int& pn0) {
+    tile_coords(p, p.tile0 + it * 256 + ((blockIdx.x & 7) << 5) + (blockIdx.x >> 3), 0, BM, BN, pm0, pn0);
+  };
+  if constexpr (PERSIST) persist_coords(0, m0, n0);
+  else ksplit = map_tile(p, BM, BN, m0, n0);
 #ifdef VLB_TOOLS
   // timing experiment: de-synchronise the CUs (every workgroup of a launch otherwise starts, and reaches its epilogue's
   // burst of memory traffic, at the same moment): odd workgroups of the first round of 256 wait p.stagger x 10 ns
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int r0 = wave * 8 + srow;
   const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
   // (tools build, timing only: ABL bit 4 / 5 make every workgroup stage W / A panel 0 - operands that always hit in L2)
-  const int rowA = (ABL & 32) ? r0 : m0 + r0, rowW = (ABL & 16) ? r0 : n0 + r0;
+  int rowA = (ABL & 32) ? r0 : m0 + r0, rowW = (ABL & 16) ? r0 : n0 + r0;       // (re-pointed per output tile by the persistent stream)
   const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
   const int nk_all = p.K / BK + p.K2 / BK;
   // split-K tail: this workgroup walks K-tiles [kt_lo, kt_lo + nk) of the concatenated (pair 1 | pair 2) sequence
@@ -771,6 +781,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       else set_operands(p.A, p.W, p.lda, p.ldw, second ? kt - nk1 : kt);
     }
     else if (kt == nk1) { if (MASKED) set_operands(p.A, p.W, p.lda, p.ldw, 0); else set_operands(p.A2, p.W2, p.lda2, p.ldw2, 0); }
+    else { curA += ROW_BYTES; curW += ROW_BYTES; }
+  };
+  // persistent stream: K-tile kt2 = kt + 2 of the CURRENT output tile, which for kt2 >= nk is K-tile kt2 - nk of the NEXT
+  // one (its coordinates in nm0 / nn0; the host guarantees nk >= 4 and K2 == 0 or K2 >= BK)
+  int nm0 = 0, nn0 = 0, p_it = 0, p_par = 0;
+  auto select_p = [&](int kt2) __attribute__((always_inline)) {
+    if (kt2 == nk) {
+      persist_coords(p_it + 1, nm0, nn0);
+      rowA = nm0 + r0; rowW = nn0 + r0;
+      set_operands(p.A, p.W, p.lda, p.ldw, 0);
+    } else if (kt2 == nk1 && kt2 < nk) { set_operands(p.A2, p.W2, p.lda2, p.ldw2, 0); }
     else { curA += ROW_BYTES; curW += ROW_BYTES; }
   };
   auto dma = [&](int buf, int i) {     // instruction i of the selected tile (0..A_LD-1: A, then W)
@@ -838,10 +859,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   W4_FENCE();
 
   // one K-tile; MORE: a tile kt+1 exists (fetch its first fragments), LOAD2: tile kt+2 exists (LDS-DMA it)
-  auto tile_k = [&](int kt, auto more_c, auto load2_c) {
+  auto tile_k = [&](int kt, auto more_c, auto load2_c) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
-    const char* sb = smem + (kt & 1) * STAGE;
-    const char* sn = smem + ((kt & 1) ^ 1) * STAGE;
+    const int buf = PERSIST ? p_par : (kt & 1);            // the stream's K-tiles alternate stages across output tiles
+    const char* sb = smem + buf * STAGE;
+    const char* sn = smem + (buf ^ 1) * STAGE;
     // ---------------- block 1: MFMA(k-step 0) || reads of k-step 1
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -862,13 +884,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     if constexpr (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (!(ABL & 4)) { W4_BARRIER(); } else { W4_FENCE(); }
-    if constexpr (LOAD2) select(kt + 2);
+    if constexpr (LOAD2) { if constexpr (PERSIST) select_p(kt + 2); else select(kt + 2); }
     // ---------------- block 2: MFMA(k-step 1) || DMA of tile kt+2 || reads of tile kt+1, k-step 0
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if constexpr (LOAD2 && !(ABL & 1)) {
-        dma(kt & 1, g);
-        if (g + NG < ND) dma(kt & 1, g + NG);
+        dma(buf, g);
+        if (g + NG < ND) dma(buf, g + NG);
       }
       if constexpr (MORE && !(ABL & 2)) {
         if (g < NT) wf[0][g] = frag(sn, b_off[0], g);
@@ -887,13 +909,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     // last (asm, hence opaque) MFMAs: XDL-write -> VALU-read needs up to 18 wait states
     asm volatile("s_nop 15" ::: "memory");
     W4_FENCE();
+    if constexpr (PERSIST) p_par ^= 1;
   };
   // Row-split K-tile (the MX-fp8 kernel's schedule, gemm_fp8.hip): the tile's MFMAs run as two blocks of NT groups, group j =
   // W fragment j (both k-steps) against row tiles 0..HM-1 (block 1) or HM..MT-1 (block 2).  W fragments are refreshed in place
   // one group behind their last use in block 2, the row halves alternate, so ONE set of fragments serves and - unlike the
   // k-step split, whose stage only frees up at the middle barrier - the W image is free early in block 1 (barrier S): the
   // LDS-DMA pieces of tile kt+2 are spread over BOTH blocks (W in block 1, A in block 2), half as dense among the MFMAs.
-  auto tile_r = [&](int kt, auto more_c, auto load2_c) {
+  auto tile_r = [&](int kt, auto more_c, auto load2_c) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
     constexpr int S_AT = 1;
     const char* sb = smem + (kt & 1) * STAGE;
@@ -960,13 +983,70 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     W4_FENCE();
   };
 #ifdef VLB_TOOLS
-  auto tile = [&](int kt, auto more_c, auto load2_c) {
+  auto tile = [&](int kt, auto more_c, auto load2_c) __attribute__((always_inline)) {
     if constexpr (ROWSPLIT) tile_r(kt, more_c, load2_c); else tile_k(kt, more_c, load2_c);
   };
 #else
   auto& tile = tile_k;                   // product build: the k-step loop, called directly (tile_r is never instantiated)
 #endif
   using T_ = std::true_type; using F_ = std::false_type;
+  if constexpr (PERSIST) {
+    // Persistent stream (tools experiment): the K loop runs on across output tiles - the last two K-tiles of a tile issue
+    // the LDS-DMA of the next tile's first two, the last one fetches its first fragments - so between two tiles only the
+    // epilogue (convert + store, no wait) and the re-zeroing of the accumulators stand in the MFMA stream: no workgroup
+    // launch, no cold prologue, no drain.
+    const int fq_ = lane >> 4;
+    auto epilogue_p = [&]() __attribute__((always_inline)) {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; j += 4)
+          asm volatile("" : "+a"(acc[i][j]), "+a"(acc[i][j + 1]), "+a"(acc[i][j + 2]), "+a"(acc[i][j + 3]));
+      if (p.act == VLB_ACT_SWIGLU_PAIR) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = m0 + wm * TM + i * 16 + fr;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < NT; j += 4)
+            store_swiglu8(p, acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq_ * 4, fq_);
+        }
+      } else {
+#define W4_EPILOGUE_P(KIND)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                      \
+    const int m = m0 + wm * TM + i * 16 + fr;                                                                           \
+    if (m >= p.M) continue;                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NT; j += 2)                                                                   \
+      w4_store_frag2<KIND>(p, acc[i][j], acc[i][j + 1], m, n0 + wn * TN + j * 16 + fq_ * 4, fq_);                       \
+  }
+        const int kind = w4_epilogue_kind(p);
+        if (kind == EPI_PLAIN) { W4_EPILOGUE_P(EPI_PLAIN) }
+        else if (kind == EPI_RESIDUAL) { W4_EPILOGUE_P(EPI_RESIDUAL) }
+        else { W4_EPILOGUE_P(EPI_GENERIC + 0) }              // (bias / no activation; the tools launch admits nothing else)
+#undef W4_EPILOGUE_P
+      }
+    };
+    for (p_it = 0; p_it < p.persist_iters; ++p_it) {
+      const bool last_tile = p_it + 1 == p.persist_iters;
+      const int n_tt = last_tile ? nk - 2 : nk;
+      for (int kt = 0; kt < n_tt; ++kt) tile(kt, T_{}, T_{});
+      if (last_tile) {
+        tile(nk - 2, T_{}, F_{});
+        tile(nk - 1, F_{}, F_{});
+      }
+      epilogue_p();
+      if (p_it + 1 < p.persist_iters) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
+        asm volatile("s_nop 7" ::: "memory");                // VALU writes of the accumulators settle before the next MFMA reads them
+        m0 = nm0; n0 = nn0;
+      }
+    }
+    return;
+  }
   int kt = 0;
   if constexpr (MASKED) {
     // K-tile 0 = the LoRA pair u.A (host guarantees K2 == 64 and nk >= 3); then keep/(1-p) on the accumulators.
@@ -1102,6 +1182,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
 
 #ifdef VLB_TOOLS
 int g_w4_rowsplit = 0;              // tools: 1 = every four-wave launch uses the row-split K loop (ABL bit 6)
+int g_w4_persist = 0;               // tools: 1 = whole-tile 256-column launches run as a persistent stream (ABL bit 7)
 #endif
 template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
@@ -1114,7 +1195,28 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     return VLB_ERR_LAUNCH;
   }
 #ifdef VLB_TOOLS
-  if constexpr (ABL == 0) {
+  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK) {
+    // tools A/B: persistent stream over the full rounds of the launch (the ragged rest as a normal launch)
+    const int nk_all = a.K / 64 + a.K2 / 64;
+    const bool act_ok = a.act == VLB_ACT_NONE || a.act == VLB_ACT_SWIGLU_PAIR;
+    if (g_w4_persist && (a.order & 2) && !(a.order & 4) && a.split_n == 1 && a.k_splits <= 1 && a.grid >= 512 && nk_all >= 4 && act_ok &&
+        (a.K2 == 0 || a.K2 >= 64)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, 128, MT, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return VLB_ERR_LAUNCH;
+      GemmArgs q = a;
+      q.persist_iters = a.grid / 256;
+      hipLaunchKernelGGL((gemm_w4_kernel<NT, 128, MT, false, false>), dim3(256), dim3(256), LDS, s, q);
+      VLB_LAUNCH_CHECK();
+      const int rest = a.grid - q.persist_iters * 256;
+      if (rest == 0) return VLB_OK;
+      GemmArgs r = a;
+      r.tile0 = a.tile0 + q.persist_iters * 256; r.grid = rest;
+      hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(r.grid), dim3(256), LDS, s, r);
+      VLB_LAUNCH_CHECK();
+      return VLB_OK;
+    }
+  }
+  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK) {
     if (g_w4_rowsplit) {                     // tools A/B: the row-split K loop
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, 64, MT, MASKED, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return VLB_ERR_LAUNCH;
@@ -1567,6 +1669,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
 // tuning hooks, libvlb_tools.so only: kernel variant / forced tile
 extern "C" void vlb_gemm_set_stagger(int ticks) { g_stagger = ticks; }
 extern "C" void vlb_gemm_set_rowsplit(int on) { g_w4_rowsplit = on; }
+extern "C" void vlb_gemm_set_persist(int on) { g_w4_persist = on; }
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;

@@ -7,7 +7,9 @@ import _toolslib  # noqa
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phantom_vlb_amd import ops
 from phantom_vlb_amd._lib import lib
-lib.vlb_gemm_set_rowsplit.argtypes = [ctypes.c_int]; lib.vlb_gemm_set_rowsplit.restype = None
+MODE = os.environ.get("VLB_AB", "rowsplit")             # rowsplit | persist (the persistent-stream experiment, ABL bit 7)
+setter = lib.vlb_gemm_set_persist if MODE == "persist" else lib.vlb_gemm_set_rowsplit
+setter.argtypes = [ctypes.c_int]; setter.restype = None
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 M = int(os.environ.get("VLB_ROWS", 5861))
 
@@ -58,12 +60,12 @@ for name, fn in cases.items():
         continue
     res_ = []
     for v in (0, 1):
-        lib.vlb_gemm_set_rowsplit(v)
+        setter(v)
         o = [q.clone() for q in outs(fn()) if torch.is_tensor(q)]
         torch.cuda.synchronize()
         res_.append((o, t(fn)))
-    lib.vlb_gemm_set_rowsplit(0)
+    setter(0)
     same = all(torch.equal(a, b) for a, b in zip(res_[0][0], res_[1][0]))
     md = max(float((a.float() - b.float()).abs().max()) for a, b in zip(res_[0][0], res_[1][0]))
-    print(f"{name:38s} equal={same} (max diff {md:.2e})  k-step {res_[0][1]:7.1f} us | row-split {res_[1][1]:7.1f} us  ({(res_[0][1] / res_[1][1] - 1) * 100:+.1f} %)", flush=True)
+    print(f"{name:38s} equal={same} (max diff {md:.2e})  product loop {res_[0][1]:7.1f} us | {MODE} {res_[1][1]:7.1f} us  ({(res_[0][1] / res_[1][1] - 1) * 100:+.1f} %)", flush=True)
     del res_
