@@ -107,7 +107,8 @@ int vlb_gemm_bf16_masked_pair_ws(const void* A, int lda, const void* W, int ldw,
  * vlb_swiglu_bwd; MistralMLP, transformers modeling_mistral.py:41-47):
  *   d_h[M,ff]   = dY[M,K].Wt[ff,K]^T + keep/(1-p) * (U[M,64].At[ff,64]^T)        (never written)
  *   dgu[:, :ff] = d_h * up * silu'(gate),   dgu[:, ff:] = d_h * silu(gate)       gate = gu[:, :ff], up = gu[:, ff:]
- * in the GEMM epilogue, from the fp32 accumulators.  Shape rules of vlb_gemm_bf16_masked_pair with N = ff. */
+ * in the GEMM epilogue, from the fp32 accumulators.  Shape rules of vlb_gemm_bf16_masked_pair with N = ff; gu and dgu rows
+ * 16-byte aligned (base pointers % 16 == 0, ldgu % 8 == 0, lddgu % 8 == 0, ff % 8 == 0): the epilogue moves 16 bytes per lane. */
 int vlb_gemm_masked_pair_swiglu_bwd(const void* dY, int lddy, const void* Wt, int ldw, const void* gu, int ldgu, void* dgu,
                                     int lddgu, int M, int ff, int K, const void* U, int ldu, const void* At, int ldat,
                                     float drop_p, uint32_t seed, void* ws, int64_t ws_bytes, void* stream);

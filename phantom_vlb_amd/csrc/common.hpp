@@ -89,6 +89,18 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + 
 // fragment j, an odd lane columns 4(fq-1)..4(fq-1)+7 of fragment j+1 - one 16-byte store each instead of two 8-byte
 // ones (half the store instructions of the serial tile tail, 64 contiguous bytes per row per instruction).
 // row = &C[m][0], n = the column of this lane's piece of fragment j (16-byte aligned for even fq).
+// The read side of the same pairing: ONE 16-byte load per lane for this lane's pieces of fragments j and j+1 of a bf16 row
+// (even fq: fragment j's columns of lanes fq, fq+1; odd fq: fragment j+1's of fq-1, fq), then the same two lane-row swaps
+// hand every lane its own two 4-column pieces.  row + n must be 16-byte aligned for even fq (as for store_pair16).
+__device__ __forceinline__ void load_pair16(const bf16* row, int n, int fq, bf16x4& a, bf16x4& b) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 l = *reinterpret_cast<const u32x4*>(row + n + ((fq & 1) ? 12 : 0));
+  const auto r0 = __builtin_amdgcn_permlane16_swap(l[0], l[2], false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(l[1], l[3], false, false);
+  a = __builtin_bit_cast(bf16x4, u32x2{r0[0], r1[0]});
+  b = __builtin_bit_cast(bf16x4, u32x2{r0[1], r1[1]});
+}
 __device__ __forceinline__ void store_pair16(bf16* row, int n, bf16x4 a, bf16x4 b, int fq) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -649,9 +649,7 @@ __device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x
 // epilogue arithmetic of one 16x16 accumulator fragment: lane holds C[m][n .. n+3]
 // SWIGLU_BWD: v = d(silu(gate)*up) for columns n..n+3 of a [M, N = ff] product; residual = the saved [gate | up] activations
 // (row stride ldr), C = [d gate | d up] (row stride ldc): SwiGLU backward without materialising v
-__device__ __forceinline__ void w4_swiglu_bwd_value(const GemmArgs& p, const f32x4& v, int m, int n, bf16x4& dg, bf16x4& du) {
-  const bf16* gp = p.residual + (int64_t)m * p.ldr + n;
-  const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(gp), u4 = *reinterpret_cast<const bf16x4*>(gp + p.N);
+__device__ __forceinline__ void w4_swiglu_bwd_math(const f32x4& v, const bf16x4& g4, const bf16x4& u4, bf16x4& dg, bf16x4& du) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float g = (float)g4[e], u = (float)u4[e];
@@ -675,9 +673,13 @@ template <int KIND>
 __device__ __forceinline__ void w4_store_frag2(const GemmArgs& p, const f32x4& va, const f32x4& vb, int m, int n, int fq) {
   bf16* crow = p.C + (int64_t)m * p.ldc;
   if constexpr (KIND == EPI_SWIGLU_BWD) {
-    bf16x4 dga, dua, dgb, dub;
-    w4_swiglu_bwd_value(p, va, m, n, dga, dua);
-    w4_swiglu_bwd_value(p, vb, m, n + 16, dgb, dub);
+    // saved [gate | up] rows: one 16-byte load each for this lane's two fragment pieces (rows 16-byte aligned: host check)
+    const bf16* grow = p.residual + (int64_t)m * p.ldr;
+    bf16x4 ga, gb, ua, ub, dga, dua, dgb, dub;
+    load_pair16(grow, n, fq, ga, gb);
+    load_pair16(grow + p.N, n, fq, ua, ub);
+    w4_swiglu_bwd_math(va, ga, ua, dga, dua);
+    w4_swiglu_bwd_math(vb, gb, ub, dgb, dub);
     store_pair16(crow, n, dga, dgb, fq);
     store_pair16(crow + p.N, n, dua, dub, fq);
   } else if constexpr (KIND == EPI_PLAIN) {
@@ -1602,8 +1604,8 @@ extern "C" int vlb_gemm_masked_pair_swiglu_bwd(const void* dY, int lddy, const v
                                                int lddgu, int M, int ff, int K, const void* U, int ldu, const void* At, int ldat,
                                                float drop_p, uint32_t seed, void* ws, int64_t ws_bytes, void* stream) {
   VLB_REQUIRE(gu && dgu, "gemm_masked_pair_swiglu_bwd: null activation pointers");
-  VLB_REQUIRE(ldgu >= 2 * ff && lddgu >= 2 * ff && ldgu % 4 == 0 && lddgu % 8 == 0 && ff % 8 == 0 && ((uintptr_t)gu % 8) == 0 && ((uintptr_t)dgu % 16) == 0,
-              "gemm_masked_pair_swiglu_bwd: [gate|up] rows must hold 2*ff columns; gu 8-byte, d gu 16-byte aligned (ff=%d ldgu=%d lddgu=%d)", ff, ldgu, lddgu);
+  VLB_REQUIRE(ldgu >= 2 * ff && lddgu >= 2 * ff && ldgu % 8 == 0 && lddgu % 8 == 0 && ff % 8 == 0 && ((uintptr_t)gu % 16) == 0 && ((uintptr_t)dgu % 16) == 0,
+              "gemm_masked_pair_swiglu_bwd: [gate|up] rows must hold 2*ff columns; gu and d gu rows 16-byte aligned (ff=%d ldgu=%d lddgu=%d)", ff, ldgu, lddgu);
   return masked_pair_impl(dY, lddy, Wt, ldw, dgu, lddgu, M, ff, K, U, ldu, At, ldat, drop_p, seed, ws, ws_bytes, stream,
                           VLB_ACT_SWIGLU_BWD, gu, ldgu);
 }
