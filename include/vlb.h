@@ -369,6 +369,15 @@ int vlb_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scal
  * x's ROW axis (rows R..Rpad-1 quantise as zeros) - the operands of the dgrad (W^T) and wgrad (dy^T, x^T) products. */
 int vlb_transpose_quantize_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, int R, int C, int Rpad,
                                  void* stream);
+/* Both of the above from ONE read of x (what the backward of an fp8 linear needs of its dy: row-wise for dgrad, transposed for
+ * wgrad); outputs bit-identical to the two separate calls.  C % 64 == 0. */
+int vlb_quantize_dual_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, void* qt, int ldqt, void* scales_t,
+                            int ldst, int R, int C, int Rpad, void* stream);
+/* Producers that emit the quantisation of their output next to the bf16 tensor (q / scales bit-identical to
+ * vlb_quantize_mxfp8 of the bf16 output): vlb_rmsnorm_fwd (dim % 32 == 0, dim <= 4096) and vlb_swiglu_fwd (ff % 32 == 0). */
+int vlb_rmsnorm_fwd_mxfp8(const void* x, const void* w, void* y, void* q, int ldq, void* scales, int lds, int rows, int dim, float eps,
+                          void* stream);
+int vlb_swiglu_fwd_mxfp8(const void* gu, void* out, void* q, int ldq, void* scales, int lds, int rows, int ff, void* stream);
 /* C[M,N] bf16 = dequant(Aq,sA)[M,K] . dequant(Wq,sW)[N,K]^T + residual (optional); fp32 accumulate.
  * N % 256 == 0, K % 128 == 0, any M. */
 int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa, const void* Wq, int ldw, const void* sW, int ldsw, void* C,

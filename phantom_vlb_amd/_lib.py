@@ -90,6 +90,9 @@ SIGNATURES = {
     "vlb_col2im3d_k2s2p1": [P, P, I, I, I, I, I, P],
     "vlb_quantize_mxfp8": [P, I, P, I, P, I, I, I, P],
     "vlb_transpose_quantize_mxfp8": [P, I, P, I, P, I, I, I, I, P],
+    "vlb_quantize_dual_mxfp8": [P, I, P, I, P, I, P, I, P, I, I, I, I, P],
+    "vlb_rmsnorm_fwd_mxfp8": [P, P, P, P, I, P, I, I, I, F, P],
+    "vlb_swiglu_fwd_mxfp8": [P, P, P, I, P, I, I, I, P],
     "vlb_gemm_mxfp8": [P, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P],
     "vlb_comm_unique_id": [P],
     "vlb_comm_init": [I, I, P, ctypes.POINTER(c_void_p)],

@@ -89,6 +89,38 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + 
 // fragment j, an odd lane columns 4(fq-1)..4(fq-1)+7 of fragment j+1 - one 16-byte store each instead of two 8-byte
 // ones (half the store instructions of the serial tile tail, 64 contiguous bytes per row per instruction).
 // row = &C[m][0], n = the column of this lane's piece of fragment j (16-byte aligned for even fq).
+// MX (OCP microscaling) block quantisation helpers shared by gemm_fp8.hip and the producer kernels that emit fp8 next to bf16:
+// shared exponent of a 32-element block = ceil(log2(amax / 448)) clamped to [-127, 127]; scale byte = E + 127.
+__device__ __forceinline__ int mx_shared_exp(float amax) {
+  int E = -127;
+  if (amax > 0.f) {
+    int e; const float f = frexpf(amax / 448.f, &e);        // amax/448 = f * 2^e, f in [0.5,1)
+    E = (f == 0.5f) ? e - 1 : e;
+    E = max(-127, min(127, E));
+  }
+  return E;
+}
+// four floats -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32: round-to-nearest-even; the scaled block never exceeds 448)
+__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d, float inv) {
+  int pk = 0;
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(a * inv, b * inv, pk, false);
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(c * inv, d * inv, pk, true);
+  return (uint32_t)pk;
+}
+// A lane holds 8 consecutive (bf16-valued) elements of a row and lanes 4q..4q+3 hold one 32-element block: quantise them
+// exactly as quantize_mxfp8_kernel does - 8 bytes per lane, the block's scale byte stored by the lane with (lane & 3) == 0.
+__device__ __forceinline__ void mx_quantize_lane8(const float (&v)[8], uint8_t* qrow, uint8_t* srow, int c, int lane) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  const int E = mx_shared_exp(amax);
+  const float inv = exp2f((float)-E);
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u32x2_*>(qrow + c) = u32x2_{mx_pack4(v[0], v[1], v[2], v[3], inv), mx_pack4(v[4], v[5], v[6], v[7], inv)};
+  if ((lane & 3) == 0) srow[c >> 5] = (uint8_t)(E + 127);
+}
 // The read side of the same pairing: ONE 16-byte load per lane for this lane's pieces of fragments j and j+1 of a bf16 row
 // (even fq: fragment j's columns of lanes fq, fq+1; odd fq: fragment j+1's of fq-1, fq), then the same two lane-row swaps
 // hand every lane its own two 4-column pieces.  row + n must be 16-byte aligned for even fq (as for store_pair16).

@@ -918,6 +918,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // one group behind their last use in block 2, the row halves alternate, so ONE set of fragments serves and - unlike the
   // k-step split, whose stage only frees up at the middle barrier - the W image is free early in block 1 (barrier S): the
   // LDS-DMA pieces of tile kt+2 are spread over BOTH blocks (W in block 1, A in block 2), half as dense among the MFMAs.
+#ifdef VLB_TOOLS
   auto tile_r = [&](int kt, auto more_c, auto load2_c) __attribute__((always_inline)) {
     constexpr bool MORE = decltype(more_c)::value, LOAD2 = decltype(load2_c)::value;
     constexpr int S_AT = 1;
@@ -984,7 +985,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     asm volatile("s_nop 15" ::: "memory");
     W4_FENCE();
   };
-#ifdef VLB_TOOLS
   auto tile = [&](int kt, auto more_c, auto load2_c) __attribute__((always_inline)) {
     if constexpr (ROWSPLIT) tile_r(kt, more_c, load2_c); else tile_k(kt, more_c, load2_c);
   };

@@ -581,6 +581,68 @@ __global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf1
   qp[0] = u32x4{w[0], w[1], w[2], w[3]};
   qp[1] = u32x4{w[4], w[5], w[6], w[7]};
 }
+// ---------------------------------------------------------------- row-wise AND transposed quantisation in one pass
+// What the backward of an fp8 linear needs of its dy: the row-wise quantisation (dgrad: dy . W^T) and the transposed one
+// (wgrad: dy^T . x) - the same 128 x 64 tile through LDS, read from memory once (2 + 1 + 1 bytes per element instead of
+// 2 + 1 and 2 + 1).  Thread t quantises the transposed block (column t & 63, rows 32 (t >> 6) ..) like
+// transpose_quantize_mxfp8_kernel, then the row block (row t >> 1, columns 32 (t & 1) ..) like quantize_mxfp8_kernel:
+// both outputs are bit-identical to the two separate kernels.  C % 64 == 0.
+__global__ __launch_bounds__(256) void quantize_dual_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+                                                                 uint8_t* __restrict__ s, int lds_, uint8_t* __restrict__ qt, int ldqt,
+                                                                 uint8_t* __restrict__ st, int ldst, int R, int C, int Rpad) {
+  __shared__ bf16 tile[128][66];
+  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (t >> 3) + 32 * p, cc = (t & 7) * 8;
+    bf16x8 v{};
+    if (r0 + r < R) v = *reinterpret_cast<const bf16x8*>(x + (int64_t)(r0 + r) * ldx + c0 + cc);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) *reinterpret_cast<bf16x2*>(&tile[r][cc + j]) = bf16x2{v[j], v[j + 1]};
+  }
+  __syncthreads();
+  {
+    const int c = t & 63, blk = t >> 6;
+    if (r0 + 32 * blk < Rpad) {
+      float v[32];
+      float amax = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) { v[k] = (float)tile[32 * blk + k][c]; amax = fmaxf(amax, fabsf(v[k])); }
+      const int E = mx_shared_exp(amax);
+      st[(int64_t)(c0 + c) * ldst + (r0 >> 5) + blk] = (uint8_t)(E + 127);
+      const float inv = exp2f((float)-E);
+      uint32_t w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
+      u32x4* qp = reinterpret_cast<u32x4*>(qt + (int64_t)(c0 + c) * ldqt + r0 + 32 * blk);
+      qp[0] = u32x4{w[0], w[1], w[2], w[3]};
+      qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+    }
+  }
+  {
+    const int r = t >> 1, hb = t & 1;
+    if (r0 + r < R) {
+      float v[32];
+      float amax = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 2) {
+        const bf16x2 e = *reinterpret_cast<const bf16x2*>(&tile[r][32 * hb + k]);
+        v[k] = (float)e[0]; v[k + 1] = (float)e[1];
+        amax = fmaxf(amax, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
+      }
+      const int E = mx_shared_exp(amax);
+      s[(int64_t)(r0 + r) * lds_ + (c0 >> 5) + hb] = (uint8_t)(E + 127);
+      const float inv = exp2f((float)-E);
+      uint32_t w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
+      u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)(r0 + r) * ldq + c0 + 32 * hb);
+      qp[0] = u32x4{w[0], w[1], w[2], w[3]};
+      qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+    }
+  }
+}
 }  // namespace
 
 #ifdef VLB_TOOLS
@@ -628,6 +690,20 @@ extern "C" int vlb_transpose_quantize_mxfp8(const void* x_bf16, int ldx, void* q
   dim3 grid((C + 63) / 64, (Rpad + 127) / 128);
   hipLaunchKernelGGL(transpose_quantize_mxfp8_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx, (uint8_t*)q, ldq,
                      (uint8_t*)scales, lds, R, C, Rpad);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+extern "C" int vlb_quantize_dual_mxfp8(const void* x_bf16, int ldx, void* q, int ldq, void* scales, int lds, void* qt, int ldqt,
+                                       void* scales_t, int ldst, int R, int C, int Rpad, void* stream) {
+  VLB_REQUIRE(x_bf16 && q && scales && qt && scales_t && R > 0 && C > 0 && C % 64 == 0 && Rpad >= R && Rpad % 32 == 0,
+              "quantize_dual_mxfp8: C must be a multiple of 64, Rpad of 32 (R=%d C=%d Rpad=%d)", R, C, Rpad);
+  VLB_REQUIRE(ldx % 8 == 0 && ldx >= C && ldq % 16 == 0 && ldq >= C && lds >= C / 32 && ldqt % 16 == 0 && ldqt >= Rpad && ldst >= Rpad / 32,
+              "quantize_dual_mxfp8: bad leading dimensions");
+  VLB_REQUIRE((((uintptr_t)x_bf16 | (uintptr_t)q | (uintptr_t)qt) % 16) == 0, "quantize_dual_mxfp8: 16-byte alignment required");
+  dim3 grid(C / 64, (Rpad + 127) / 128);
+  hipLaunchKernelGGL(quantize_dual_mxfp8_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx, (uint8_t*)q, ldq,
+                     (uint8_t*)scales, lds, (uint8_t*)qt, ldqt, (uint8_t*)scales_t, ldst, R, C, Rpad);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

@@ -112,6 +112,38 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_cached_kernel(const bf16* __r
   }
 }
 
+// RMSNorm that also emits the MX-fp8 quantisation of its output (what the fp8 linear behind it consumes): y as above, plus
+// q / s bit-identical to vlb_quantize_mxfp8(y) - the quantiser sees the bf16-rounded y.  dim % 32 == 0, dim <= NI*512.
+template <int NI>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, bf16* __restrict__ y,
+                                                            uint8_t* __restrict__ q, int ldq, uint8_t* __restrict__ s, int lds_,
+                                                            int rows, int dim, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bf16* xr = x + (int64_t)row * dim;
+  bf16x8 xb[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) { const int c = lane * 8 + k * 512; xb[k] = c < dim ? *reinterpret_cast<const bf16x8*>(xr + c) : bf16x8{}; }
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float v = (float)xb[k][i]; ss += v * v; }
+  const float rstd = rsqrtf(wave_sum(ss) / dim + eps);
+  bf16* yr = y + (int64_t)row * dim;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int c = lane * 8 + k * 512;
+    if (c < dim) {                       // (dim % 32 == 0: the four lanes of a block are in or out together)
+      float g[8], v[8]; load8(w + c, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (float)(bf16)(g[i] * (float)(bf16)((float)xb[k][i] * rstd));
+      store8(yr + c, v);
+      mx_quantize_lane8(v, q + (int64_t)row * ldq, s + (int64_t)row * lds_, c, lane);
+    }
+  }
+}
+
 template <int NI>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_cached_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                                  const bf16* __restrict__ dy, const bf16* __restrict__ dx_in,
@@ -280,6 +312,20 @@ __global__ void swiglu_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) g[i] = silu_f(g[i]) * u[i];
     store8(out + r * ff + c, g);
+  }
+}
+// SwiGLU forward that also emits the MX-fp8 quantisation of its output (the down projection's operand); ff % 32 == 0, so
+// four consecutive work items (= lanes) always cover one 32-element block of one row.
+__global__ void swiglu_fwd_q8_kernel(const bf16* __restrict__ gu, bf16* __restrict__ out, uint8_t* __restrict__ q, int ldq,
+                                     uint8_t* __restrict__ s, int lds_, int ff, int64_t total) {
+  const int cpr = ff >> 3;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / cpr; const int c = (idx % cpr) * 8;
+    float g[8], u[8]; load8(gu + r * 2 * ff + c, g); load8(gu + r * 2 * ff + ff + c, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = (float)(bf16)(silu_f(g[i]) * u[i]);
+    store8(out + r * ff + c, g);
+    mx_quantize_lane8(g, q + r * ldq, s + r * lds_, c, threadIdx.x & 63);
   }
 }
 __global__ void swiglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dout, bf16* __restrict__ dgu,
@@ -573,6 +619,19 @@ extern "C" int vlb_rmsnorm_fwd(const void* x, const void* w, void* y, int rows, 
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
+extern "C" int vlb_rmsnorm_fwd_mxfp8(const void* x, const void* w, void* y, void* q, int ldq, void* scales, int lds, int rows, int dim,
+                                     float eps, void* stream) {
+  ROWS_KERNEL_CHECK("rmsnorm_fwd_mxfp8");
+  VLB_REQUIRE(q && scales && dim % 32 == 0 && dim <= 4096 && ldq >= dim && ldq % 8 == 0 && lds >= dim / 32 && ((uintptr_t)q % 8) == 0,
+              "rmsnorm_fwd_mxfp8: dim must be a multiple of 32, at most 4096; q rows 8-byte aligned (dim=%d ldq=%d)", dim, ldq);
+#define VLB_RQ_ARGS dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const bf16*)x, (const bf16*)w, (bf16*)y, (uint8_t*)q, ldq, \
+                    (uint8_t*)scales, lds, rows, dim, eps
+  if (dim <= 512) hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<1>, VLB_RQ_ARGS);
+  else hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<8>, VLB_RQ_ARGS);
+#undef VLB_RQ_ARGS
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
 extern "C" int vlb_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dx_in, void* dx, int rows,
                                int dim, float eps, void* stream) {
   ROWS_KERNEL_CHECK("rmsnorm_bwd");
@@ -613,6 +672,15 @@ extern "C" int vlb_swiglu_fwd(const void* gu, void* out, int rows, int ff, void*
   const int64_t total = (int64_t)rows * (ff / 8);
   hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), (const bf16*)gu,
                      (bf16*)out, ff, total);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+extern "C" int vlb_swiglu_fwd_mxfp8(const void* gu, void* out, void* q, int ldq, void* scales, int lds, int rows, int ff, void* stream) {
+  VLB_REQUIRE(rows > 0 && ff % 32 == 0 && q && scales && ldq >= ff && ldq % 8 == 0 && lds >= ff / 32 && ((uintptr_t)q % 8) == 0,
+              "swiglu_fwd_mxfp8: ff=%d must be a multiple of 32; q rows 8-byte aligned", ff);
+  const int64_t total = (int64_t)rows * (ff / 8);
+  hipLaunchKernelGGL(swiglu_fwd_q8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), (const bf16*)gu, (bf16*)out,
+                     (uint8_t*)q, ldq, (uint8_t*)scales, lds, ff, total);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }

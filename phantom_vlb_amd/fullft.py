@@ -16,6 +16,8 @@ reduce-scatters layer chunks under the remaining backward and shards the 12 B/pa
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -31,6 +33,11 @@ CONN_LN = ("bn1", "bn2", "bn3", "dsbn")                                      # (
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# fp8 path: quantisations produced by the kernel that writes the bf16 tensor (rmsnorm / SwiGLU) or from one read for both layouts
+# (dy and W: row-wise + transposed).  VLB_FP8_FUSED_QUANT=0 runs the separate quantise passes instead (A/B; results identical).
+FUSED_QUANT = os.environ.get("VLB_FP8_FUSED_QUANT", "1") == "1"
 
 
 def _up(n, m):
@@ -167,12 +174,19 @@ class FullFineTune:
         if self.fp8:      # quantised W for the forward, quantised W^T (straight from W, one pass) for dgrad
             for li, lw in enumerate(self.w.layers):
                 for k in ("wqkv", "wo", "wgu", "wdown"):
-                    self.wq[(li, k)] = ops.quantize_mxfp8(lw[k], *self.wq.get((li, k), (None, None)))
                     N, K = lw[k].shape
                     old = self.wq.get((li, k + "_t"))
                     if old is None:
                         old = (torch.empty(K, N, dtype=torch.uint8, device=self.dev), torch.empty(K, N // 32, dtype=torch.uint8, device=self.dev))
-                    self.wq[(li, k + "_t")] = ops.transpose_quantize_mxfp8(lw[k], old[0], old[1], N)
+                    if FUSED_QUANT and K % 64 == 0 and N % 32 == 0:         # both quantisations from ONE read of W (vlb_quantize_dual_mxfp8)
+                        row = self.wq.get((li, k))
+                        if row is None:
+                            row = (torch.empty(N, K, dtype=torch.uint8, device=self.dev), torch.empty(N, K // 32, dtype=torch.uint8, device=self.dev))
+                        ops.quantize_dual_mxfp8(lw[k], row[0], row[1], old[0], old[1], N)
+                        self.wq[(li, k)], self.wq[(li, k + "_t")] = row, old
+                    else:
+                        self.wq[(li, k)] = ops.quantize_mxfp8(lw[k], *self.wq.get((li, k), (None, None)))
+                        self.wq[(li, k + "_t")] = ops.transpose_quantize_mxfp8(lw[k], old[0], old[1], N)
         dw_f = getattr(self, "dw_flipped", None)
         if dw_f is None:
             dw_f = self.dw_flipped = {}
@@ -198,14 +212,18 @@ class FullFineTune:
         ops.transpose_pad(x, buf, Mp)
         return buf[:C, :Mp]
 
-    def wgrad(self, dy, x, out, dyT=None, xT=None, fp8=False):
+    def wgrad(self, dy, x, out, dyT=None, xT=None, fp8=False, dyTq=None):
         """out[N, K] (bf16 view into the flat gradient buffer) = dy[M,N]^T . x[M,K].  fp8: both transposed operands are
-        quantised along the token axis (MX blocks of 32 tokens) and the product runs on the MX-fp8 MFMA GEMM."""
+        quantised along the token axis (MX blocks of 32 tokens) and the product runs on the MX-fp8 MFMA GEMM; ``dyTq``:
+        the transposed quantisation of dy when `_dual` already produced it."""
         if fp8 and out.shape[1] % 256 == 0:
             Mp = _up(dy.shape[0], 128)
-            qa, sa = self._qbuf("dyTq", dy.shape[1], Mp)
+            if dyTq is None:
+                qa, sa = self._qbuf("dyTq", dy.shape[1], Mp)
+                ops.transpose_quantize_mxfp8(dy, qa, sa, Mp)      # transpose and quantise in one pass (3 B/element)
+            else:
+                qa, sa = dyTq
             qb, sb = self._qbuf("xTq", x.shape[1], Mp)
-            ops.transpose_quantize_mxfp8(dy, qa, sa, Mp)          # transpose and quantise in one pass (3 B/element)
             ops.transpose_quantize_mxfp8(x, qb, sb, Mp)
             ops.gemm_mxfp8(qa, sa, qb, sb, out=out)
             return
@@ -221,13 +239,33 @@ class FullFineTune:
             buf = self._tb[tag] = (torch.empty(need, dtype=torch.uint8, device=self.dev), torch.empty(need // 32, dtype=torch.uint8, device=self.dev))
         return buf[0][:need].view(rows, cols), buf[1][:need // 32].view(rows, cols // 32)
 
-    def _lin(self, x, li, key, residual=None):
-        """x @ W^T (+ residual) for decoder weight `key` of layer li: bf16 MFMA GEMM, or the MX-fp8 one."""
+    def _lin(self, x, li, key, residual=None, xq=None):
+        """x @ W^T (+ residual) for decoder weight `key` of layer li: bf16 MFMA GEMM, or the MX-fp8 one.  ``xq``: (e4m3, scales)
+        of x when its producer already emitted them (rmsnorm_mxfp8 / swiglu_mxfp8 / quantize_dual_mxfp8)."""
         if self.fp8:
-            xq, xs = ops.quantize_mxfp8(x)
+            xq, xs = ops.quantize_mxfp8(x) if xq is None else xq
             wq, ws = self.wq[(li, key)]
             return ops.gemm_mxfp8(xq, xs, wq, ws, residual=residual)
         return ops.gemm(x, self.w.layers[li][key], residual=residual)
+
+    def _norm(self, x, wn):
+        """(h, quantised h or None): RMSNorm; on the fp8 path the kernel emits the MX quantisation of h in the same pass."""
+        if self.fp8 and FUSED_QUANT and x.shape[1] % 32 == 0 and x.shape[1] <= 4096:
+            h, q, s = ops.rmsnorm_mxfp8(x, wn, self.g.rms_eps)
+            return h, (q, s)
+        return ops.rmsnorm(x, wn, self.g.rms_eps), None
+
+    def _dual(self, dy):
+        """Row-wise and transposed MX quantisation of a backward signal from one read (dgrad and wgrad operands of one linear);
+        None when the shape does not fit the fused kernel (the callers then quantise separately)."""
+        if not self.fp8 or not FUSED_QUANT or dy.shape[1] % 64 != 0:
+            return None
+        M, C = dy.shape
+        Mp = _up(M, 128)
+        q, s = self._qbuf("dyq", M, C)
+        qt, st = self._qbuf("dyTq", C, Mp)
+        ops.quantize_dual_mxfp8(dy, q, s, qt, st, Mp)
+        return (q, s), (qt, st)
 
     # ------------------------------------------------------------------ connector (training forward + backward)
     def _block_fwd(self, x, blk, N, H, save):
@@ -335,16 +373,20 @@ class FullFineTune:
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         self.saved = []
         for li, lw in enumerate(w.layers):
-            h1 = ops.rmsnorm(x, lw["in_norm"], g.rms_eps)
-            qkv = self._lin(h1, li, "wqkv")
+            h1, h1q = self._norm(x, lw["in_norm"])
+            qkv = self._lin(h1, li, "wqkv", xq=h1q)
             ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
             a, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, g.heads, g.kv_heads, g.head_dim,
                                        True, g.head_dim ** -0.5, key_mask=key_mask, need_lse=True, layout=layout)
             x2 = self._lin(a, li, "wo", residual=x)
-            h2 = ops.rmsnorm(x2, lw["post_norm"], g.rms_eps)
-            gu = self._lin(h2, li, "wgu")
-            hh = ops.swiglu(gu)
-            x3 = self._lin(hh, li, "wdown", residual=x2)
+            h2, h2q = self._norm(x2, lw["post_norm"])
+            gu = self._lin(h2, li, "wgu", xq=h2q)
+            if self.fp8 and FUSED_QUANT and gu.shape[1] % 64 == 0:
+                hh, hq, hs = ops.swiglu_mxfp8(gu)
+                x3 = self._lin(hh, li, "wdown", residual=x2, xq=(hq, hs))
+            else:
+                hh = ops.swiglu(gu)
+                x3 = self._lin(hh, li, "wdown", residual=x2)
             self.saved.append(dict(x=x, h1=h1, qkv=qkv, a=a, lse=lse, x2=x2, h2=h2, gu=gu, hh=hh))
             x = x3
         self.x_last, self.key_mask, self.B, self.layout = x, key_mask, B, layout
@@ -364,20 +406,24 @@ class FullFineTune:
             lw, sv = w.layers[li], self.saved[li]
             pre = f"layers.{li}"
             # MLP: x3 = x2 + down(silu(gate) * up)
-            self.wgrad(dx, sv["hh"], G(f"{pre}.wdown"), fp8=self.fp8)
-            d_hh = self._lin(dx, li, "wdown_t")
+            dq_ = self._dual(dx) or (None, None)               # dx quantised both ways from one read
+            self.wgrad(dx, sv["hh"], G(f"{pre}.wdown"), fp8=self.fp8, dyTq=dq_[1])
+            d_hh = self._lin(dx, li, "wdown_t", xq=dq_[0])
             d_gu = ops.swiglu_bwd(sv["gu"], d_hh)
-            self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"), fp8=self.fp8)
-            d_h2 = self._lin(d_gu, li, "wgu_t")
+            dq_ = self._dual(d_gu) or (None, None)
+            self.wgrad(d_gu, sv["h2"], G(f"{pre}.wgu"), fp8=self.fp8, dyTq=dq_[1])
+            d_h2 = self._lin(d_gu, li, "wgu_t", xq=dq_[0])
             dx2 = ops.rmsnorm_bwd_full(sv["x2"], lw["post_norm"], d_h2, g.rms_eps, G(f"{pre}.post_norm"), dx_in=dx)
             # attention: x2 = x + o(attn(rope(qkv(norm(x)))))
-            self.wgrad(dx2, sv["a"], G(f"{pre}.wo"), fp8=self.fp8)
-            d_a = self._lin(dx2, li, "wo_t")
+            dq_ = self._dual(dx2) or (None, None)
+            self.wgrad(dx2, sv["a"], G(f"{pre}.wo"), fp8=self.fp8, dyTq=dq_[1])
+            d_a = self._lin(dx2, li, "wo_t", xq=dq_[0])
             dqkv = ops.attention_bwd(sv["qkv"], qd, kd, sv["a"], d_a, sv["lse"], self.key_mask, B, S, g.heads, g.kv_heads,
                                      g.head_dim, True, g.head_dim ** -0.5, layout=layout, delta=delta)
             ops.rope_(dqkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, sign=-1, pos=pos)
-            self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"), fp8=self.fp8)
-            d_h1 = self._lin(dqkv, li, "wqkv_t")
+            dq_ = self._dual(dqkv) or (None, None)
+            self.wgrad(dqkv, sv["h1"], G(f"{pre}.wqkv"), fp8=self.fp8, dyTq=dq_[1])
+            d_h1 = self._lin(dqkv, li, "wqkv_t", xq=dq_[0])
             dx = ops.rmsnorm_bwd_full(sv["x"], lw["in_norm"], d_h1, g.rms_eps, G(f"{pre}.in_norm"), dx_in=dx2)
             self.saved[li] = None
             if self.grad_hook is not None:

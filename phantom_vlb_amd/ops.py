@@ -552,6 +552,39 @@ def transpose_quantize_mxfp8(x, q, s, rows_pad):
     return q, s
 
 
+def quantize_dual_mxfp8(x, q, s, qt, st, rows_pad):
+    """Row-wise (q [R, C], s [R, C/32]) and transposed (qt [C, rows_pad], st [C, rows_pad/32]) MX quantisation of x[R, C] from one
+    read of x; both bit-identical to quantize_mxfp8 / transpose_quantize_mxfp8."""
+    R, C = x.shape
+    assert x.stride(1) == 1 and q.shape == (R, C) and s.shape == (R, C // 32) and qt.shape == (C, rows_pad) and st.shape == (C, rows_pad // 32)
+    check(lib.vlb_quantize_dual_mxfp8(_dev(x).data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), qt.data_ptr(),
+                                      qt.stride(0), st.data_ptr(), st.stride(0), R, C, rows_pad, _stream()), "vlb_quantize_dual_mxfp8")
+    return q, s, qt, st
+
+
+def rmsnorm_mxfp8(x, w, eps, q=None, s=None):
+    """(y, q, s): RMSNorm plus the MX-fp8 quantisation of y in the same pass."""
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    q = torch.empty(rows, dim, dtype=torch.uint8, device=x.device) if q is None else q
+    s = torch.empty(rows, dim // 32, dtype=torch.uint8, device=x.device) if s is None else s
+    check(lib.vlb_rmsnorm_fwd_mxfp8(_dev(x).data_ptr(), w.data_ptr(), y.data_ptr(), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0),
+                                    rows, dim, eps, _stream()), "vlb_rmsnorm_fwd_mxfp8")
+    return y, q, s
+
+
+def swiglu_mxfp8(gu, q=None, s=None):
+    """(h, q, s): silu(gate) * up plus the MX-fp8 quantisation of h in the same pass."""
+    rows, ff2 = gu.shape
+    ff = ff2 // 2
+    out = torch.empty(rows, ff, dtype=BF16, device=gu.device)
+    q = torch.empty(rows, ff, dtype=torch.uint8, device=gu.device) if q is None else q
+    s = torch.empty(rows, ff // 32, dtype=torch.uint8, device=gu.device) if s is None else s
+    check(lib.vlb_swiglu_fwd_mxfp8(_dev(gu).data_ptr(), out.data_ptr(), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), rows, ff,
+                                   _stream()), "vlb_swiglu_fwd_mxfp8")
+    return out, q, s
+
+
 def gemm_mxfp8(aq, sa, wq, sw, residual=None, out=None):
     """out[M,N] bf16 = dequant(aq, sa) @ dequant(wq, sw)^T + residual."""
     M, K = aq.shape

@@ -51,6 +51,45 @@ def test_transpose_quantize_equals_quantize_of_the_transpose(dev):
         assert torch.equal(s, s2) and torch.equal(q, q2), (R, C)
 
 
+def test_quantize_dual_equals_the_two_separate_kernels(dev):
+    """vlb_quantize_dual_mxfp8: row-wise + transposed quantisation of a backward signal from ONE read - both outputs bit-identical
+    to vlb_quantize_mxfp8 / vlb_transpose_quantize_mxfp8 (ragged row counts, a column slice of a wider tensor)."""
+    from phantom_vlb_amd import ops
+    torch.manual_seed(5)
+    for R, C, ld in ((300, 192, 256), (5861, 1024, 1024), (77, 64, 64), (128, 6144, 6144)):
+        full = (torch.randn(R, ld) * torch.logspace(-3, 2, R)[:, None]).to(BF).to(dev)
+        x = full[:, :C]
+        Rp = (R + 127) // 128 * 128
+        q = torch.full((R, C), 0x55, dtype=torch.uint8, device=dev); s = torch.full((R, C // 32), 0x55, dtype=torch.uint8, device=dev)
+        qt = torch.full((C, Rp), 0x55, dtype=torch.uint8, device=dev); st = torch.full((C, Rp // 32), 0x55, dtype=torch.uint8, device=dev)
+        ops.quantize_dual_mxfp8(x, q, s, qt, st, Rp)
+        q1, s1 = ops.quantize_mxfp8(x)
+        qt1 = torch.empty_like(qt); st1 = torch.empty_like(st)
+        ops.transpose_quantize_mxfp8(x, qt1, st1, Rp)
+        assert torch.equal(q, q1) and torch.equal(s, s1), (R, C)
+        assert torch.equal(qt, qt1) and torch.equal(st, st1), (R, C)
+
+
+def test_producers_emit_the_quantisation_of_their_output(dev):
+    """vlb_rmsnorm_fwd_mxfp8 / vlb_swiglu_fwd_mxfp8: same bf16 output as the plain kernels, and q / scales bit-identical to
+    quantising that output afterwards."""
+    from phantom_vlb_amd import ops
+    torch.manual_seed(6)
+    for rows, dim in ((301, 4096), (77, 256), (5861, 1024)):
+        x = (torch.randn(rows, dim) * torch.logspace(-2, 2, rows)[:, None]).to(BF).to(dev)
+        w = (1 + 0.1 * torch.randn(dim)).to(BF).to(dev)
+        y, q, s = ops.rmsnorm_mxfp8(x, w, 1e-5)
+        y0 = ops.rmsnorm(x, w, 1e-5)
+        q0, s0 = ops.quantize_mxfp8(y0)
+        assert torch.equal(y, y0) and torch.equal(q, q0) and torch.equal(s, s0), (rows, dim)
+    for rows, ff in ((301, 14336), (77, 64), (1000, 352)):
+        gu = (torch.randn(rows, 2 * ff) * 2).to(BF).to(dev)
+        h, q, s = ops.swiglu_mxfp8(gu)
+        h0 = ops.swiglu(gu)
+        q0, s0 = ops.quantize_mxfp8(h0)
+        assert torch.equal(h, h0) and torch.equal(q, q0) and torch.equal(s, s0), (rows, ff)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 1024), (5861, 1024, 4096), (77, 256, 256),
                                    (5861, 4096, 512),      # 368 tiles: one full round + 112 tiles re-cut into 256x128 halves
                                    (3000, 3072, 256)])     # 144 tiles: everything runs as halves

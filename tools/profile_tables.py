@@ -98,6 +98,28 @@ def stats(d, steps, prefix, note=""):
     print(open(f"profiles/{prefix}_kernel_groups.txt").read())
     # gate/up call from the trace (timed steps only)
     tr = win
+    f8 = [r for r in tr if "gemm_mxfp8" in r["Kernel_Name"]]
+    if f8:          # --fp8 run: the gate/up projection is a vlb_gemm_mxfp8 call = whole-tile launch (largest grid) + the re-cut halves
+        key = "Grid_Size_X" if "Grid_Size_X" in f8[0] else "Grid_Size"
+        whole = [r for r in f8 if re.search(r"kernel<8", r["Kernel_Name"])]
+        gmax = max(int(r[key]) for r in whole)
+        idx = {id(r): i for i, r in enumerate(tr)}
+        dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        main_l = [r for r in whole if int(r[key]) == gmax]
+        # the forward gate/up call only: its dgrad twin (N = 4096, K = 28672) has a smaller grid; the wgrad one has another N
+        dm, tails = [dur(r) for r in main_l], []
+        for r in main_l:
+            j = idx[id(r)] + 1
+            tails.append(dur(tr[j]) if j < len(tr) and "gemm_mxfp8" in tr[j]["Kernel_Name"] and re.search(r"kernel<4", tr[j]["Kernel_Name"]) else 0.0)
+        call = sum(dm) / len(dm) + sum(tails) / len(tails)
+        with open(f"profiles/{prefix}_gateup_gemm_launches.csv", "w") as o:
+            o.write("# gate/up GEMM call of the --fp8 run = gemm_mxfp8 whole-tile launch (largest grid) + the 256x128 re-cut launch of its partial last round; "
+                    "us, from the kernel trace; peak = 5000 TFLOP/s (dense fp8 MFMA)\n")
+            o.write(f"main_launches,{len(dm)},avg_us,{sum(dm) / len(dm):.2f},min_us,{min(dm):.2f},max_us,{max(dm):.2f}\n")
+            o.write(f"tail_launches,{len(tails)},avg_us,{sum(tails) / len(tails):.2f}\n")
+            o.write(f"call_avg_us,{call:.2f},tflops,{2.0 * M * 2 * FF * E / call / 1e6:.1f},frac_of_5000,{2.0 * M * 2 * FF * E / call / 1e6 / 5000.0:.4f}\n")
+        print(open(f"profiles/{prefix}_gateup_gemm_launches.csv").read())
+        return
     w4 = [r for r in tr if re.search(r"gemm_w4_kernel<8, 0, 8, false, false>", r["Kernel_Name"])]
     if not w4:
         return
