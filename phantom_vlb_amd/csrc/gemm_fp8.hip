@@ -535,17 +535,15 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const bf16* __restr
 }
 // ---------------------------------------------------------------- transpose + quantise in one pass
 // q[C, Rpad] (e4m3) and s[C, Rpad/32] (E8M0) of x[R, C]^T: what the dgrad (W^T) and wgrad (dy^T, x^T) GEMMs of the fp8
-// path consume - MX blocks run along the ORIGINAL row axis.  Tile 128 (R) x 64 (C) through LDS: 16-byte global loads
-// along C, then one thread per (output row c, 32-element block of R): 32 LDS reads down a column, amax, shared
-// exponent, v_cvt_pk_fp8_f32, one 32-byte store.  Rows R..Rpad-1 quantise as zeros (scale byte 0).
-__global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
-                                                                      uint8_t* __restrict__ s, int lds_, int R, int C, int Rpad) {
-  __shared__ bf16 tile[128][66];
-  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
-  const int t = threadIdx.x;
+// path consume - MX blocks run along the ORIGINAL row axis.  Tile 128 (R) x 128 (C) through LDS (row stride 65 words:
+// column walks are conflict-free): 16-byte global loads along C, then one thread per (column PAIR, 32-row block): 32 4-byte
+// LDS reads down the pair, two amax / shared exponents, v_cvt_pk_fp8_f32, two 32-byte stores.  Rows R..Rpad-1 quantise as
+// zeros (scale byte 0).  (Round 2 read one column per thread with 2-byte LDS reads from a 64-column tile: 3.5 TB/s.)
+constexpr int TQ_COLS = 128, TQ_LD = 130;
+__device__ __forceinline__ void tq_load_tile(bf16 (*tile)[TQ_LD], const bf16* __restrict__ x, int ldx, int r0, int c0, int R, int C, int t) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = (t >> 3) + 32 * p, cc = (t & 7) * 8;
+  for (int p = 0; p < 8; ++p) {
+    const int r = (t >> 4) + 16 * p, cc = (t & 15) * 8;
     bf16x8 v{};
     if (r0 + r < R) {
       if (c0 + cc + 8 <= C) v = *reinterpret_cast<const bf16x8*>(x + (int64_t)(r0 + r) * ldx + c0 + cc);
@@ -554,94 +552,114 @@ __global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf1
 #pragma unroll
     for (int j = 0; j < 8; j += 2) *reinterpret_cast<bf16x2*>(&tile[r][cc + j]) = bf16x2{v[j], v[j + 1]};
   }
+}
+// Transposed blocks of one thread: columns c0 + 2cp, +1; source rows r0 + 32 blk ..: quantised into registers (w[h][8] = 32
+// bytes of output row c0 + 2cp + h, scale bytes sc[h]).
+__device__ __forceinline__ void tq_quantize_pair(const bf16 (*tile)[TQ_LD], int t, uint32_t (&w)[2][8], uint8_t (&sc)[2]) {
+  const int cp = t & 63, blk = t >> 6;
+  float v0[32], v1[32];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const bf16x2 e = *reinterpret_cast<const bf16x2*>(&tile[32 * blk + k][2 * cp]);
+    v0[k] = (float)e[0]; v1[k] = (float)e[1];
+    a0 = fmaxf(a0, fabsf(v0[k])); a1 = fmaxf(a1, fabsf(v1[k]));
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float (&v)[32] = h ? v1 : v0;
+    const int E = mx_shared_exp(h ? a1 : a0);
+    sc[h] = (uint8_t)(E + 127);
+    const float inv = exp2f((float)-E);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[h][i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
+  }
+}
+// The quantised tile leaves through LDS (the bf16 image is dead by then - callers synchronise first): out[c][128 source rows] as
+// 144-byte rows plus the 4 scale bytes of every column, so that the global stores are whole 128-byte output-row segments (8 lanes
+// x 16 bytes) instead of one 32-byte piece per lane scattered over 64 output rows.
+constexpr int TQ_OUT_LD = 144;
+__device__ __forceinline__ void tq_stage_and_store(char* stage, const uint32_t (&w)[2][8], const uint8_t (&sc)[2], uint8_t* __restrict__ q, int ldq,
+                                                   uint8_t* __restrict__ s, int lds_, int r0, int c0, int C, int Rpad, int t) {
+  const int cp = t & 63, blk = t >> 6;
+  uint8_t* sstage = reinterpret_cast<uint8_t*>(stage) + TQ_COLS * TQ_OUT_LD;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4* o = reinterpret_cast<u32x4*>(stage + (2 * cp + h) * TQ_OUT_LD + 32 * blk);
+    o[0] = u32x4{w[h][0], w[h][1], w[h][2], w[h][3]};
+    o[1] = u32x4{w[h][4], w[h][5], w[h][6], w[h][7]};
+    sstage[(2 * cp + h) * 4 + blk] = sc[h];
+  }
   __syncthreads();
-  const int c = t & 63, blk = t >> 6;                      // output row c0 + c, block of 32 source rows r0 + 32*blk ..
-  if (c0 + c >= C || r0 + 32 * blk >= Rpad) return;
-  float v[32];
-  float amax = 0.f;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) { v[k] = (float)tile[32 * blk + k][c]; amax = fmaxf(amax, fabsf(v[k])); }
-  int E = -127;
-  if (amax > 0.f) {
-    int e; const float f = frexpf(amax / 448.f, &e);
-    E = (f == 0.5f) ? e - 1 : e;
-    E = max(-127, min(127, E));
+  for (int it = 0; it < 4; ++it) {
+    const int c = it * 32 + (t >> 3), seg = t & 7;
+    if (c0 + c < C && r0 + 16 * seg < Rpad)
+      *reinterpret_cast<u32x4*>(q + (int64_t)(c0 + c) * ldq + r0 + 16 * seg) = *reinterpret_cast<const u32x4*>(stage + c * TQ_OUT_LD + 16 * seg);
   }
-  s[(int64_t)(c0 + c) * lds_ + (r0 >> 5) + blk] = (uint8_t)(E + 127);
-  const float inv = exp2f((float)-E);
-  uint32_t w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int pk = 0;
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 4] * inv, v[i * 4 + 1] * inv, pk, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 4 + 2] * inv, v[i * 4 + 3] * inv, pk, true);
-    w[i] = (uint32_t)pk;
+  if (t < TQ_COLS && c0 + t < C) {
+    uint8_t* sp = s + (int64_t)(c0 + t) * lds_ + (r0 >> 5);
+    const int nb = min(4, (Rpad - r0) >> 5);
+    if (nb == 4 && (lds_ & 3) == 0 && ((uintptr_t)s & 3) == 0) *reinterpret_cast<uint32_t*>(sp) = *reinterpret_cast<const uint32_t*>(sstage + t * 4);
+    else for (int i = 0; i < nb; ++i) sp[i] = sstage[t * 4 + i];
   }
-  u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)(c0 + c) * ldq + r0 + 32 * blk);
-  qp[0] = u32x4{w[0], w[1], w[2], w[3]};
-  qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+}
+__global__ __launch_bounds__(256) void transpose_quantize_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+                                                                      uint8_t* __restrict__ s, int lds_, int R, int C, int Rpad) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[128][TQ_LD];
+  static_assert(sizeof(bf16) * 128 * TQ_LD >= TQ_COLS * TQ_OUT_LD + TQ_COLS * 4, "the output staging reuses the tile's LDS");
+  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * TQ_COLS;
+  const int t = threadIdx.x;
+  tq_load_tile(tile, x, ldx, r0, c0, R, C, t);
+  __syncthreads();
+  uint32_t w[2][8]; uint8_t sc[2];
+  tq_quantize_pair(tile, t, w, sc);
+  __syncthreads();                                         // every thread is done reading the bf16 image
+  tq_stage_and_store(reinterpret_cast<char*>(&tile[0][0]), w, sc, q, ldq, s, lds_, r0, c0, C, Rpad, t);
 }
 // ---------------------------------------------------------------- row-wise AND transposed quantisation in one pass
-// What the backward of an fp8 linear needs of its dy: the row-wise quantisation (dgrad: dy . W^T) and the transposed one
-// (wgrad: dy^T . x) - the same 128 x 64 tile through LDS, read from memory once (2 + 1 + 1 bytes per element instead of
-// 2 + 1 and 2 + 1).  Thread t quantises the transposed block (column t & 63, rows 32 (t >> 6) ..) like
-// transpose_quantize_mxfp8_kernel, then the row block (row t >> 1, columns 32 (t & 1) ..) like quantize_mxfp8_kernel:
-// both outputs are bit-identical to the two separate kernels.  C % 64 == 0.
+// What the backward of an fp8 linear needs of its dy (and the refresh of a weight needs of W): the row-wise quantisation
+// (dgrad: dy . W^T) and the transposed one (wgrad: dy^T . x) - the same 128 x 128 tile through LDS, read from memory once
+// (2 + 1 + 1 bytes per element instead of 2 + 1 and 2 + 1).  Every thread quantises its transposed column pair like
+// transpose_quantize_mxfp8_kernel and two row blocks (row t >> 1, columns 64 (t & 1) + {0, 32} ..) like
+// quantize_mxfp8_kernel: both outputs are bit-identical to the two separate kernels.  C % 64 == 0.
 __global__ __launch_bounds__(256) void quantize_dual_mxfp8_kernel(const bf16* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
                                                                  uint8_t* __restrict__ s, int lds_, uint8_t* __restrict__ qt, int ldqt,
                                                                  uint8_t* __restrict__ st, int ldst, int R, int C, int Rpad) {
-  __shared__ bf16 tile[128][66];
-  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * 64;
+  __shared__ __attribute__((aligned(16))) bf16 tile[128][TQ_LD];
+  const int r0 = blockIdx.y * 128, c0 = blockIdx.x * TQ_COLS;
   const int t = threadIdx.x;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = (t >> 3) + 32 * p, cc = (t & 7) * 8;
-    bf16x8 v{};
-    if (r0 + r < R) v = *reinterpret_cast<const bf16x8*>(x + (int64_t)(r0 + r) * ldx + c0 + cc);
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) *reinterpret_cast<bf16x2*>(&tile[r][cc + j]) = bf16x2{v[j], v[j + 1]};
-  }
+  tq_load_tile(tile, x, ldx, r0, c0, R, C, t);
   __syncthreads();
-  {
-    const int c = t & 63, blk = t >> 6;
-    if (r0 + 32 * blk < Rpad) {
-      float v[32];
-      float amax = 0.f;
+  uint32_t w[2][8]; uint8_t sc[2];
+  tq_quantize_pair(tile, t, w, sc);
+  const int r = t >> 1;
+  if (r0 + r < R) {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { v[k] = (float)tile[32 * blk + k][c]; amax = fmaxf(amax, fabsf(v[k])); }
-      const int E = mx_shared_exp(amax);
-      st[(int64_t)(c0 + c) * ldst + (r0 >> 5) + blk] = (uint8_t)(E + 127);
-      const float inv = exp2f((float)-E);
-      uint32_t w[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
-      u32x4* qp = reinterpret_cast<u32x4*>(qt + (int64_t)(c0 + c) * ldqt + r0 + 32 * blk);
-      qp[0] = u32x4{w[0], w[1], w[2], w[3]};
-      qp[1] = u32x4{w[4], w[5], w[6], w[7]};
-    }
-  }
-  {
-    const int r = t >> 1, hb = t & 1;
-    if (r0 + r < R) {
+    for (int hb = 0; hb < 2; ++hb) {
+      const int cb = 64 * (t & 1) + 32 * hb;               // first column of this block inside the tile
+      if (c0 + cb >= C) break;
       float v[32];
       float amax = 0.f;
 #pragma unroll
       for (int k = 0; k < 32; k += 2) {
-        const bf16x2 e = *reinterpret_cast<const bf16x2*>(&tile[r][32 * hb + k]);
+        const bf16x2 e = *reinterpret_cast<const bf16x2*>(&tile[r][cb + k]);
         v[k] = (float)e[0]; v[k + 1] = (float)e[1];
         amax = fmaxf(amax, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
       }
       const int E = mx_shared_exp(amax);
-      s[(int64_t)(r0 + r) * lds_ + (c0 >> 5) + hb] = (uint8_t)(E + 127);
+      s[(int64_t)(r0 + r) * lds_ + ((c0 + cb) >> 5)] = (uint8_t)(E + 127);
       const float inv = exp2f((float)-E);
-      uint32_t w[8];
+      uint32_t wr[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
-      u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)(r0 + r) * ldq + c0 + 32 * hb);
-      qp[0] = u32x4{w[0], w[1], w[2], w[3]};
-      qp[1] = u32x4{w[4], w[5], w[6], w[7]};
+      for (int i = 0; i < 8; ++i) wr[i] = mx_pack4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], inv);
+      u32x4* qp = reinterpret_cast<u32x4*>(q + (int64_t)(r0 + r) * ldq + c0 + cb);
+      qp[0] = u32x4{wr[0], wr[1], wr[2], wr[3]};
+      qp[1] = u32x4{wr[4], wr[5], wr[6], wr[7]};
     }
   }
+  __syncthreads();                                         // every thread is done reading the bf16 image
+  tq_stage_and_store(reinterpret_cast<char*>(&tile[0][0]), w, sc, qt, ldqt, st, ldst, r0, c0, C, Rpad, t);
 }
 }  // namespace
 
@@ -687,7 +705,7 @@ extern "C" int vlb_transpose_quantize_mxfp8(const void* x_bf16, int ldx, void* q
   VLB_REQUIRE(x_bf16 && q && scales && R > 0 && C > 0 && Rpad >= R && Rpad % 32 == 0 && ldx % 8 == 0 && ldx >= C && ldq % 16 == 0 &&
                   ldq >= Rpad && lds >= Rpad / 32, "transpose_quantize_mxfp8: Rpad must be a multiple of 32, ldx of 8, ldq of 16");
   VLB_REQUIRE((((uintptr_t)x_bf16 | (uintptr_t)q) % 16) == 0, "transpose_quantize_mxfp8: 16-byte alignment required");
-  dim3 grid((C + 63) / 64, (Rpad + 127) / 128);
+  dim3 grid((C + TQ_COLS - 1) / TQ_COLS, (Rpad + 127) / 128);
   hipLaunchKernelGGL(transpose_quantize_mxfp8_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx, (uint8_t*)q, ldq,
                      (uint8_t*)scales, lds, R, C, Rpad);
   VLB_LAUNCH_CHECK();
@@ -701,7 +719,7 @@ extern "C" int vlb_quantize_dual_mxfp8(const void* x_bf16, int ldx, void* q, int
   VLB_REQUIRE(ldx % 8 == 0 && ldx >= C && ldq % 16 == 0 && ldq >= C && lds >= C / 32 && ldqt % 16 == 0 && ldqt >= Rpad && ldst >= Rpad / 32,
               "quantize_dual_mxfp8: bad leading dimensions");
   VLB_REQUIRE((((uintptr_t)x_bf16 | (uintptr_t)q | (uintptr_t)qt) % 16) == 0, "quantize_dual_mxfp8: 16-byte alignment required");
-  dim3 grid(C / 64, (Rpad + 127) / 128);
+  dim3 grid((C + TQ_COLS - 1) / TQ_COLS, (Rpad + 127) / 128);
   hipLaunchKernelGGL(quantize_dual_mxfp8_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16*)x_bf16, ldx, (uint8_t*)q, ldq,
                      (uint8_t*)scales, lds, (uint8_t*)qt, ldqt, (uint8_t*)scales_t, ldst, R, C, Rpad);
   VLB_LAUNCH_CHECK();
