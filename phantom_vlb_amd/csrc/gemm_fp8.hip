@@ -234,13 +234,16 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(Fp8Args p, Fp8Launch
 //                       last MFMA group that uses it
 // so the register file holds one set of fragments (8 + NT), the DMA pieces are spread over both blocks, and each piece has
 // one to two blocks (1000-3000 matrix cycles) to land.  Scale bytes are fetched with ds_read_u8 (byte g of the row's word).
-template <int NT, int S_AT>
+// MT = 8: 256-row tiles (wave block 128 rows); MT = 6: 192-row tiles (wave block 96 rows), picked by the host when they
+// quantise the row count into fewer, fuller rounds of tiles (plan_fp8_rows).
+template <int NT, int S_AT, int MT = 8>
 __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8Launch L) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = 256 * FROW, WROWS = 32 * NT, W_BYTES = WROWS * FROW;
+  constexpr int AROWS = 32 * MT, HM = MT / 2;
+  constexpr int A_BYTES = AROWS * FROW, WROWS = 32 * NT, W_BYTES = WROWS * FROW;
   constexpr int SA_OFF = A_BYTES + W_BYTES, SW_OFF = SA_OFF + 256 * 4;
   constexpr int STAGE = SW_OFF + 256 * 4;
-  constexpr int NW = NT + 1, NA = 9;                         // LDS-DMA pieces per wave per K-tile: W image + scale words, A image + scale words
+  constexpr int NW = NT + 1, NA = MT + 1;                       // LDS-DMA pieces per wave per K-tile: W image + scale words, A image + scale words
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int w;
@@ -258,14 +261,14 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
   const int band = t / (8 * p.tiles_m), c0 = band * 8, within = t - band * 8 * p.tiles_m;
   const int band_cols = min(8, p.tiles_n - c0);
   const int tm = within / band_cols, tn = c0 + within % band_cols;
-  const int m0 = tm * 256, n0 = tn * 256 + half * 128;
+  const int m0 = tm * AROWS, n0 = tn * 256 + half * 128;
   const int nk = p.K / FBK;
 
   // LDS-DMA sources = uniform base (advanced 128 B per K-tile) + one 32-bit byte offset per piece (host checks the extents)
-  uint32_t offA[8], offW[NT];
+  uint32_t offA[MT], offW[NT];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int r = wave * 64 + j * 8 + (lane >> 3), s = lane & 7;
+  for (int j = 0; j < MT; ++j) {
+    const int r = wave * 8 * MT + j * 8 + (lane >> 3), s = lane & 7;
     offA[j] = (uint32_t)min(m0 + r, p.M - 1) * (uint32_t)p.lda + (uint32_t)((s ^ ((r >> 1) & 7)) * 16);
   }
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
     const int r = wave * 8 * NT + j * 8 + (lane >> 3), s = lane & 7;
     offW[j] = (uint32_t)(n0 + r) * (uint32_t)p.ldw + (uint32_t)((s ^ ((r >> 1) & 7)) * 16);
   }
-  const uint32_t offSA = (uint32_t)min(m0 + wave * 64 + lane, p.M - 1) * (uint32_t)p.ldsa;
+  const uint32_t offSA = (uint32_t)min(m0 + (wave * 64 + lane) % AROWS, p.M - 1) * (uint32_t)p.ldsa;
   const uint32_t offSW = (uint32_t)(n0 + (wave * 64 + lane) % WROWS) * (uint32_t)p.ldsw;
   const char* const baseA = reinterpret_cast<const char*>(p.A); const char* const baseW = reinterpret_cast<const char*>(p.W);
   const char* const baseSA = reinterpret_cast<const char*>(p.sA); const char* const baseSW = reinterpret_cast<const char*>(p.sW);
@@ -282,19 +285,19 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
     if (pc < NT) glds16f(baseW + (int64_t)kt * FBK + offW[pc], base + A_BYTES + (wave * NT + pc) * 1024);
     else glds4f(baseSW + kt * 4 + offSW, base + SW_OFF + wave * 256);
   };
-  auto dmaA = [&](int st, int kt, int pc) {                  // piece pc of A(kt): 0..7 image, 8 scale words
+  auto dmaA = [&](int st, int kt, int pc) {                  // piece pc of A(kt): 0..MT-1 image, MT scale words
     char* base = smem + st * STAGE;
-    if (pc < 8) glds16f(baseA + (int64_t)kt * FBK + offA[pc], base + (wave * 8 + pc) * 1024);
+    if (pc < MT) glds16f(baseA + (int64_t)kt * FBK + offA[pc], base + (wave * MT + pc) * 1024);
     else glds4f(baseSA + kt * 4 + offSA, base + SA_OFF + wave * 256);
   };
   const int fr = lane & 15, g = lane >> 4;
-  f32x4 acc[NT][8];
+  f32x4 acc[NT][MT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  i32x8 wf[NT], af[8];
-  int swb[NT], sab[8];
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8 wf[NT], af[MT];
+  int swb[NT], sab[MT];
   auto readW = [&](const char* sb, int j) {
     const int r = wn * 16 * NT + j * 16 + fr;
     const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + A_BYTES + f_off(r, g));
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
     swb[j] = *reinterpret_cast<const uint8_t*>(sb + SW_OFF + r * 4 + g);
   };
   auto readA = [&](const char* sb, int i) {
-    const int r = wm * 128 + i * 16 + fr;
+    const int r = wm * 16 * MT + i * 16 + fr;
     const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + f_off(r, g));
     const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + f_off(r, 4 + g));
     af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
 #pragma unroll
   for (int j = 0; j < NT - 1; ++j) readW(smem, j);           // (fragment NT-1 is fetched at the top of every tile)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) readA(smem, i);
+  for (int i = 0; i < HM; ++i) readA(smem, i);
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // so that no compiler-inserted full wait lands at the loop header
   VLB_FENCE();
 
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
     // ---------------- block 1: W fragment j x activation rows 0..3 || reads of rows 4..7 || DMA of W(kt+2)
     readW(sb, NT - 1);                                       // the one W fragment block 2 of the previous tile could not refresh in time
 #pragma unroll
-    for (int i = 4; i < 8; ++i) readA(sb, i);
+    for (int i = HM; i < MT; ++i) readA(sb, i);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if constexpr (LOAD2) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < HM; ++i) {
         const int sc = swb[j] | (sab[i] << 8);
         acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
       }
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
     // ---------------- block 2: W fragment j x activation rows 4..7 || DMA of A(kt+2) || reads of tile kt+1
     if constexpr (MORE) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) readA(sn, i);
+      for (int i = 0; i < HM; ++i) readA(sn, i);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
       }
       if constexpr (MORE) { if (j >= 1) readW(sn, j - 1); }  // in place: fragment j-1 died with the previous group
 #pragma unroll
-      for (int i = 4; i < 8; ++i) {
+      for (int i = HM; i < MT; ++i) {
         const int sc = swb[j] | (sab[i] << 8);
         acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[j][i], 0, 0, 0, sc, 1, sc);
       }
@@ -409,8 +412,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
   auto rows = [&](auto res_c, auto wide_c) {
     constexpr bool RES = decltype(res_c)::value, WIDE = decltype(wide_c)::value;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wm * 128 + i * 16 + fr;
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * 16 * MT + i * 16 + fr;
       if (m >= p.M) continue;
       bf16* crow = p.C + (int64_t)m * p.ldc;
 #pragma unroll
@@ -439,14 +442,22 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_pipe_kernel(Fp8Args p, Fp8L
 }
 
 #ifdef VLB_TOOLS
+int g_fp8_rows = 0;                 // tools: 0 = planner, 256 / 192 = forced tile height
 int g_fp8_variant = 1;              // tools: 0 = read-phase kernel (rounds 1-2), 1 = pipelined kernel
 #else
 constexpr int g_fp8_variant = 1;
 #endif
 
-template <int NT>
+template <int NT, int MT = 8>
 int launch_fp8(const Fp8Args& a, Fp8Launch L, int grid, hipStream_t st) {
-  constexpr int LDS = 2 * (256 * FROW + 32 * NT * FROW + 2 * 256 * 4);
+  constexpr int LDS = 2 * (32 * MT * FROW + 32 * NT * FROW + 2 * 256 * 4);
+  if constexpr (MT != 8) {
+    static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mxfp8_pipe_kernel<NT, 1, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr6 != hipSuccess) { vlb_set_error("gemm_mxfp8: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr6)); return VLB_ERR_LAUNCH; }
+    hipLaunchKernelGGL((gemm_mxfp8_pipe_kernel<NT, 1, MT>), dim3(grid), dim3(256), LDS, st, a, L);
+    VLB_LAUNCH_CHECK();
+    return VLB_OK;
+  }
 #ifdef VLB_TOOLS
   if (g_fp8_variant == 2 || g_fp8_variant == 3) {            // tools: barrier S in front of MFMA group 2 / 0 instead of 1
     auto k = g_fp8_variant == 2 ? &gemm_mxfp8_pipe_kernel<NT, 2> : &gemm_mxfp8_pipe_kernel<NT, 0>;
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(256) void quantize_dual_mxfp8_kernel(const bf16* __
 }  // namespace
 
 #ifdef VLB_TOOLS
-extern "C" void vlb_gemm_mxfp8_set_variant(int v) { g_fp8_variant = v; }
+extern "C" void vlb_gemm_mxfp8_set_variant(int v) { g_fp8_variant = v & 0xff; g_fp8_rows = v >> 8; }     // rows in bits 8.. (0: planner)
 // tools build only: ONE v_mfma_scale_f32_16x16x128_f8f6f4 on caller-given per-lane registers (layout experiments)
 namespace {
 template <int OA, int OB>
@@ -736,18 +747,35 @@ extern "C" int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa,
               "gemm_mxfp8: misaligned operand");
   if (residual) VLB_REQUIRE(ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 8) == 0, "gemm_mxfp8: bad residual");
   VLB_REQUIRE((int64_t)M * lda < (1ll << 32) && (int64_t)N * ldw < (1ll << 32), "gemm_mxfp8: operands above 4 GiB are not supported (32-bit staging offsets)");
-  Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
-            M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + 255) / 256, N / 256};
-  // One workgroup per CU: the GEMM runs in rounds of 256 tiles.  When the last round is at most 5/8 full its tiles
-  // are re-cut into 256 x 128 halves in a second launch (twice the workgroups, about 0.55 of a round each).
+  // One workgroup per CU: the GEMM runs in rounds of 256 tiles.  A partial last round that is at most 5/8 full is re-cut into
+  // 256 x 128 (or 192 x 128) halves in a second launch (twice the workgroups, about 0.62 of a round).  192-row tiles are picked
+  // when they quantise the row count into cheaper rounds: cost = rounds x tile rows, the smaller tile charged 2 % more (the rule
+  // of the bf16 kernel, gemm.hip plan_rows, without split-K tails).
   hipStream_t st = as_stream(stream);
-  const int tiles = a.tiles_m * a.tiles_n, cus = 256, rem = tiles % cus;
-  if (tiles > cus / 2 && rem > 0 && rem <= cus * 5 / 8) {
+  const int cus = 256, tn = N / 256;
+  auto plan = [&](int rows, int& tiles, int& rem, bool& halves) {
+    tiles = ((M + rows - 1) / rows) * tn; rem = tiles % cus;
+    halves = tiles > cus / 2 && rem > 0 && rem <= cus * 5 / 8;
+    return (tiles / cus + (rem == 0 ? 0.0 : halves ? 0.62 : 1.0)) * rows;
+  };
+  int t256, r256, t192, r192; bool h256, h192;
+  const double c256 = plan(256, t256, r256, h256), c192 = plan(192, t192, r192, h192) * 1.02;
+  bool use192 = t256 > cus && c192 < 0.97 * c256;
+#ifdef VLB_TOOLS
+  if (g_fp8_rows == 256) use192 = false;
+  if (g_fp8_rows == 192) use192 = true;
+  if (g_fp8_variant != 1) use192 = false;
+#endif
+  const int rows = use192 ? 192 : 256, tiles = use192 ? t192 : t256, rem = use192 ? r192 : r256;
+  const bool halves = use192 ? h192 : h256;
+  Fp8Args a{(const uint8_t*)Aq, (const uint8_t*)sA, (const uint8_t*)Wq, (const uint8_t*)sW, (bf16*)C, (const bf16*)residual,
+            M, N, K, lda, ldw, ldc, ldr, ldsa, ldsw, (M + rows - 1) / rows, tn};
+  if (halves) {
     if (tiles - rem > 0) {
-      int rc = launch_fp8<8>(a, Fp8Launch{0, 1}, tiles - rem, st);
+      int rc = use192 ? launch_fp8<8, 6>(a, Fp8Launch{0, 1}, tiles - rem, st) : launch_fp8<8>(a, Fp8Launch{0, 1}, tiles - rem, st);
       if (rc != VLB_OK) return rc;
     }
-    return launch_fp8<4>(a, Fp8Launch{tiles - rem, 2}, 2 * rem, st);
+    return use192 ? launch_fp8<4, 6>(a, Fp8Launch{tiles - rem, 2}, 2 * rem, st) : launch_fp8<4>(a, Fp8Launch{tiles - rem, 2}, 2 * rem, st);
   }
-  return launch_fp8<8>(a, Fp8Launch{0, 1}, tiles, st);
+  return use192 ? launch_fp8<8, 6>(a, Fp8Launch{0, 1}, tiles, st) : launch_fp8<8>(a, Fp8Launch{0, 1}, tiles, st);
 }

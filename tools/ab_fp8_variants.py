@@ -20,7 +20,9 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-VARIANTS = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
+# variant word: bits 0-7 kernel (0 = round-2 read-phase kernel, 1 = pipelined, 2 / 3 = barrier S elsewhere), bits 8.. forced tile
+# rows (0 = planner): 65537 = pipelined with 256-row tiles, 49153 = pipelined with 192-row tiles, 1 = pipelined, planner's choice
+VARIANTS = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1").split(",")]
 shapes = [("tiny", 77, 256, 128), ("k256", 300, 512, 256), ("k384", 300, 512, 384), ("halves", 3000, 3072, 256), ("qkv", 5861, 6144, 4096), ("o", 5861, 4096, 4096),
           ("gate_up", 5861, 28672, 4096), ("down", 5861, 4096, 14336), ("d_gu", 5861, 4096, 28672), ("d_down", 5861, 14336, 4096),
           ("wgrad gu", 28672, 4096, 5888), ("gate_up M=10240", 10240, 28672, 4096), ("sq8192", 8192, 8192, 8192)]
