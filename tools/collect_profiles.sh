@@ -21,6 +21,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 python3 tools/profile_tables.py stats gpurun_out/pf/full8 4 r03_bench_full7b_fp8 > gpurun_out/pf/full8_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/full -- python3 bench.py --workload full --steps 4 --warmup 2 > gpurun_out/pf/full.log 2>&1
 python3 tools/profile_tables.py stats gpurun_out/pf/full 4 r03_bench_full7b > gpurun_out/pf/full_tables.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch8 -- python3 bench.py --workload full --fp8 --steps 1 --warmup 1 > gpurun_out/pf/fetch8.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write8 -- python3 bench.py --workload full --fp8 --steps 1 --warmup 1 > gpurun_out/pf/write8.log 2>&1
+python3 tools/profile_tables.py traffic_fp8 gpurun_out/pf/fetch8 gpurun_out/pf/write8 profiles/r03_gemm_gateup_hbm_traffic_fp8.csv > gpurun_out/pf/traffic8_tables.log 2>&1
 python3 tools/bench_hbm_kernels.py > profiles/r03_hbm_bound_kernels.txt 2> gpurun_out/pf/hbm.err
 mkdir -p gpurun_out/pf/out && cp profiles/r03_* profiles/gateup_traffic.json gpurun_out/pf/out/
 for f in gpurun_out/pf/*_tables.log; do echo "== $f"; tail -n 4 $f; done

@@ -214,6 +214,46 @@ def traffic(dfetch, dwrite, out):
     json.dump(tab, open(jp, "w"), indent=1)
 
 
+def traffic_fp8(dfetch, dwrite, out):
+    """Same for the --fp8 run: one vlb_gemm_mxfp8 gate/up call = whole-tile launch (largest grid) + the re-cut launch behind it."""
+    res = {}
+    for d, c in ((dfetch, "FETCH_SIZE"), (dwrite, "WRITE_SIZE")):
+        f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+        rs = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
+        rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+        whole = [r for r in rs if "gemm_mxfp8" in r["Kernel_Name"] and re.search(r"kernel<8", r["Kernel_Name"])]
+        grid = max(int(r["Grid_Size"]) for r in whole)
+        pos = {r["Dispatch_Id"]: i for i, r in enumerate(rs)}
+        mains, tails = [], []
+        for r in whole:
+            if int(r["Grid_Size"]) != grid:
+                continue
+            mains.append(float(r["Counter_Value"]))
+            j = pos[r["Dispatch_Id"]] + 1
+            tails.append(float(rs[j]["Counter_Value"]) if j < len(rs) and "gemm_mxfp8" in rs[j]["Kernel_Name"] and re.search(r"kernel<4", rs[j]["Kernel_Name"]) else 0.0)
+        res[c] = (grid, len(mains), sum(mains) / len(mains), sum(tails) / len(tails))
+    fm, ft = res["FETCH_SIZE"][2], res["FETCH_SIZE"][3]
+    wm, wt = res["WRITE_SIZE"][2], res["WRITE_SIZE"][3]
+    total = (2 * (fm + ft) + wm + wt) * 1024
+    alg = (M * E + 2 * FF * E) * (1 + 1 / 32) + 2.0 * M * 2 * FF
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --workload full --fp8 --steps 1 --warmup 1`\n")
+        o.write("# one gate/up vlb_gemm_mxfp8 CALL = whole-tile gemm_mxfp8_pipe_kernel launch (largest grid) + the re-cut half-tile launch of its partial last round; KB per call, means over the calls of the run\n")
+        o.write("# gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
+        o.write("counter,main_grid_threads,calls,main_mean_kb,tail_mean_kb\n")
+        for c, (g, n, a, b) in res.items():
+            o.write(f"{c},{g},{n},{a:.1f},{b:.1f}\n")
+        o.write(f"# traffic per call = {total:.4e} bytes; algorithmic {alg:.4e} (e4m3 A + W with E8M0 scales, C [M,N] bf16); ratio {total / alg:.2f}\n")
+    print(open(out).read())
+    import json
+    jp = "profiles/gateup_traffic.json"
+    tab = json.load(open(jp)) if os.path.exists(jp) else {}
+    tab[f"fp8:{M},{2 * FF},{E}"] = {"bytes": float(f"{total:.4e}"), "source": out,
+                                   "what": "--workload full --fp8: vlb_gemm_mxfp8 gate/up call = whole-tile launch + re-cut halves"}
+    json.dump(tab, open(jp, "w"), indent=1)
+
+
 if __name__ == "__main__":
     {"stats": lambda: stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else ""), "sq": lambda: sq(sys.argv[2], sys.argv[3]),
-     "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4])}[sys.argv[1]]()
+     "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4]),
+     "traffic_fp8": lambda: traffic_fp8(sys.argv[2], sys.argv[3], sys.argv[4])}[sys.argv[1]]()
