@@ -29,13 +29,13 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH
 PEAK_FP8_TFLOPS = 5000.0       # dense fp8 / MX-fp8 MFMA (same source; the headline figures with 2:1 sparsity are never used)
 
 
-def gateup_traffic(shape, fp8=False):
+def gateup_traffic(shape, prefix=""):
     """L2->fabric bytes of ONE gate/up GEMM call of this (M, N, K), as measured with rocprofv3 --pmc (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 2x read correction) and recorded by `tools/profile_tables.py traffic` in the tracked file
     profiles/gateup_traffic.json - the line and profiles/ cannot disagree.  (bytes, source file) or (None, None)."""
     try:
         with open(os.path.join(ROOT, "profiles", "gateup_traffic.json")) as f:
-            e = json.load(f).get(("fp8:" if fp8 else "") + "%d,%d,%d" % tuple(shape))
+            e = json.load(f).get(prefix + "%d,%d,%d" % tuple(shape))
         return (float(e["bytes"]), e["source"]) if e else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None
@@ -265,7 +265,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches, (pM, pN, pK) = probe.result()
-    traffic, traffic_src = gateup_traffic((pM, pN, pK), fp8=a.fp8)
+    # the recorded collections are per call KIND: LoRA / frozen calls under the bare shape, the fp8 call under "fp8:", the plain
+    # bf16 call of the full fine-tune (no collection on record) under "full:"
+    traffic, traffic_src = gateup_traffic((pM, pN, pK), "fp8:" if a.fp8 else "full:" if full else "")
     if rank == 0:
         clips = world * B * a.steps
         value = clips / dt
