@@ -25,6 +25,9 @@ def main():
                   ("d_gu", 5861, 4096, 28672), ("d_down", 5861, 14336, 4096)]
     if os.environ.get("VLB_SHAPES") == "frozen":        # the frozen batch (M = 9447 packed rows)
         shapes = [("qkv", 9447, 6144, 4096), ("o", 9447, 4096, 4096), ("gate_up", 9447, 28672, 4096), ("down", 9447, 4096, 14336)]
+    if os.environ.get("VLB_SHAPES") == "vit":           # the CLIP tower at the LoRA batch: 3 clips x 12 frames x 577 tokens, width 1024
+        shapes = [("vit_qkv", 20772, 3072, 1024), ("vit_out", 20772, 1024, 1024), ("vit_fc1", 20772, 4096, 1024), ("vit_fc2", 20772, 1024, 4096),
+                  ("conn_1x1", 20736, 4096, 4096), ("conn_in", 20736, 4096, 1024)]
     if os.environ.get("VLB_SHAPES", "").startswith("rows="):   # VLB_SHAPES=rows=31200: the decoder projections at another row count
         M = int(os.environ["VLB_SHAPES"][5:])
         shapes = [("qkv", M, 6144, 4096), ("o", M, 4096, 4096), ("gate_up", M, 28672, 4096), ("down", M, 4096, 14336)]
