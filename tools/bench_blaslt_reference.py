@@ -24,6 +24,9 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
+if os.environ.get("VLB_SHAPES") == "lora":     # the LoRA batch (5861 packed rows): forward and dgrad shapes of the decoder
+    shapes = [(5861, 6144, 4096, "qkv"), (5861, 4096, 4096, "o"), (5861, 28672, 4096, "gate/up"), (5861, 4096, 14336, "down"),
+              (5861, 4096, 6144, "dgrad qkv"), (5861, 4096, 28672, "dgrad gate/up"), (5861, 14336, 4096, "dgrad down")]
 for M, N, K, name in shapes:
     a = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
     w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
