@@ -88,7 +88,9 @@ def prep_text(scene_text: str, seg_text: str, word_lists: Sequence[Sequence[str]
     Dialogue of the frame window = the words of its TRs joined by single spaces, each token inheriting its word's onset
     (a silent window becomes the text "No dialogue." with TWO dummy onsets 0.5 / 1.0, whatever number of tokens that text has:
     ``masking_params`` then says dialog_len = 2 - a quirk of the reference kept as is); the scene text spoken before the window is cut from
-    the LEFT so that everything fits ``max_tokens`` with an 80-token allowance for instructions and system message."""
+    the LEFT so that everything fits ``max_tokens`` with an 80-token allowance for instructions and system message (a budget
+    <= 0 is not a cut to nothing: Python's ``tokens[-0:]`` / ``tokens[k:]``, unreachable with 866 slots; pinned against the
+    reference's own output in tests/test_cpu_ref_fixtures.py)."""
     all_words = [w for wl in word_lists for w in wl]
     all_onsets = [o for ol in onset_lists for o in ol]
     if len(all_words) != len(all_onsets):
@@ -106,7 +108,7 @@ def prep_text(scene_text: str, seg_text: str, word_lists: Sequence[Sequence[str]
     seg_len = len(tokenizer.tokenize(seg_dialog.strip()))
     max_scene = max_tokens - (80 + seg_len)
     if len(tokens) > max_scene:
-        tokens = tokens[-max_scene:] if max_scene > 0 else []
+        tokens = tokens[-max_scene:]       # the reference's slice as is: a budget of 0 keeps everything, -k drops the first k
     background = tokenizer.convert_tokens_to_string(tokens).strip()
     inst_len = len(tokenizer.tokenize(INSTRUCTION.strip()))
     instructions = f"{INSTRUCTION.strip()} {seg_dialog.strip()}"

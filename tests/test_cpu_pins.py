@@ -50,6 +50,80 @@ def test_pin_mistral_decoder_against_transformers():
     gen_golden.pin_mistral(O.geometry_mini())
 
 
+@pytest.mark.skipif(not (have_reference and have_transformers), reason="the reference tree only exists in the build container")
+def test_committed_reference_fixtures_equal_a_fresh_run_of_the_reference():
+    """tests/golden/ref_{weight_mask.npz,linear_names.json,datamodule.json} == what the reference's own make_weight_mask /
+    find_all_linear_names / datamodule produce today (oracle/gen_ref_fixtures.generate(): the python3.10 side)."""
+    import json
+    import gen_ref_fixtures as G
+    fresh = G.generate()
+    gold = np.load(os.path.join(GOLD, "ref_weight_mask.npz"))
+    assert set(gold.files) == set(fresh["weight_mask"])
+    for k in gold.files:
+        assert np.array_equal(gold[k], np.asarray(fresh["weight_mask"][k])), k
+    for name in ("linear_names", "datamodule"):
+        with open(os.path.join(GOLD, f"ref_{name}.json")) as f:
+            assert json.load(f) == json.loads(json.dumps(fresh[name])), name
+
+
+@pytest.mark.skipif(not (have_reference and os.path.exists("/opt/conda/bin/python3.9")), reason="build container only")
+def test_committed_reference_pipeline_files_equal_a_fresh_run_of_the_reference(tmp_path):
+    """tests/golden/ref_pipeline/ == what the reference's extractfeatures / lazyloading scripts write today
+    (oracle/gen_ref_fixtures_py39.py re-run into a scratch directory; datasets compared one by one)."""
+    import json
+    import subprocess
+    from phantom_vlb_amd import h5lite
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    env["VLB_REF_PIPELINE_OUT"] = str(tmp_path / "ref_pipeline")
+    subprocess.run(["/opt/conda/bin/python3.9", "-W", "ignore", os.path.join(ROOT, "oracle", "gen_ref_fixtures_py39.py")],
+                   check=True, env=env, capture_output=True)
+    gold_dir = os.path.join(GOLD, "ref_pipeline")
+
+    def walk(g, prefix=""):
+        for k in g.keys():
+            item = g[k]
+            if hasattr(item, "keys"):
+                yield from walk(item, f"{prefix}{k}/")
+            else:
+                yield f"{prefix}{k}", np.array(item)
+
+    files = sorted(os.path.relpath(os.path.join(dp, fn), gold_dir) for dp, _, fns in os.walk(gold_dir) for fn in fns)
+    fresh_dir = env["VLB_REF_PIPELINE_OUT"]
+    assert files == sorted(os.path.relpath(os.path.join(dp, fn), fresh_dir) for dp, _, fns in os.walk(fresh_dir) for fn in fns)
+    for rel in files:
+        if rel.endswith(".json"):
+            with open(os.path.join(gold_dir, rel)) as a, open(os.path.join(fresh_dir, rel)) as b:
+                assert json.load(a) == json.load(b)
+            continue
+        a, b = dict(walk(h5lite.File(os.path.join(gold_dir, rel)))), dict(walk(h5lite.File(os.path.join(fresh_dir, rel))))
+        assert a.keys() == b.keys(), rel
+        for k in a:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (rel, k)
+
+
+@pytest.mark.skipif(not have_transformers, reason="transformers not importable")
+def test_clip_preprocess_equals_the_hf_clip_image_processor():
+    """extract.clip_preprocess (the processor the reference gets from the CLIP tower, extractfeatures.py:148-177,345-347)
+    against transformers' CLIPImageProcessor configured as openai/clip-vit-large-patch14-336's preprocessor_config.json
+    (shortest edge 336 bicubic, centre crop 336, rescale 1/255, OpenAI mean / std) on square frames."""
+    import warnings
+    from PIL import Image
+    from phantom_vlb_amd import extract as X
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from transformers import CLIPImageProcessor
+        proc = CLIPImageProcessor(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}, do_resize=True,
+                                  do_center_crop=True, do_rescale=True, do_normalize=True, do_convert_rgb=True, resample=3,
+                                  image_mean=list(X.CLIP_MEAN), image_std=list(X.CLIP_STD))
+    rng = np.random.RandomState(0)
+    frames = [rng.randint(0, 256, (480, 480, 3), dtype=np.uint8), rng.randint(0, 256, (336, 336, 3), dtype=np.uint8),
+              rng.randint(0, 256, (200, 200, 3), dtype=np.uint8)]
+    want = np.stack([np.asarray(proc.preprocess([Image.fromarray(f)])["pixel_values"][0]) for f in frames])
+    got = X.clip_preprocess(frames, 336)
+    assert got.shape == want.shape == (3, 3, 336, 336) and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 1e-6
+
+
 @pytest.mark.parametrize("tag", ["frozen", "lora"])
 def test_committed_goldens_equal_a_fresh_generation(tag):
     import gen_golden

@@ -421,6 +421,22 @@ def test_weight_mask_matches_oracle_and_kat(dev):
         assert torch.allclose(row.cpu()[0], torch.from_numpy(kat[f"{i}_row"]))
 
 
+@pytest.mark.parametrize("tag", ["g7b", "g2f"])
+def test_weight_mask_kernel_equals_the_reference_generated_rows(dev, tag):
+    """tests/golden/ref_weight_mask.npz was written by the reference's OWN make_weight_mask
+    (src/litmodule/videollama2_vlb_litmodule.py:178-203, run by oracle/gen_ref_fixtures.py): 40 (pad_len, inst_len,
+    dialog_len) triples at the 7B geometry incl. (0,9,0), (300,9,58), (0,0,0), and a 2-frame geometry.  Bit-exact in bf16."""
+    import numpy as np
+    import os
+    from phantom_vlb_amd import ops
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_weight_mask.npz"))
+    pv, vw, lw = (torch.from_numpy(z[f"{tag}_{k}"]).to(dev) for k in ("padvals", "vis_weights", "lang_weights"))
+    got = ops.weight_mask(pv, vw, lw, 169, int(z[f"{tag}_max_len"]), round_bf16=True)
+    bits = got.cpu().to(BF).view(torch.int16).numpy().view(np.uint16)
+    assert bits.shape == z[f"{tag}_rows_bf16_bits"].shape and np.array_equal(bits, z[f"{tag}_rows_bf16_bits"])
+    assert torch.equal(got.cpu(), got.cpu().to(BF).float())        # round_bf16 rows are bf16-representable
+
+
 # ------------------------------------------------------------------ brain head fwd + bwd vs oracle autograd
 @pytest.mark.parametrize("B,S,E,V,drop", [(4, 128, 512, 128, False), (3, 96, 1024, 200, True), (5, 64, 4096, 256, False)])
 def test_head_fwd_bwd(dev, B, S, E, V, drop):
