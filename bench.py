@@ -299,7 +299,7 @@ def main():
                                       "note": "padded tail rows (ids == 0) are not computed, like the reference's flash-attn unpadding; results identical"},
                        # executed FLOPs: the per-clip figure scaled by the rows actually run (conservative: the vision tower is not reduced)
                        "step_tflops_per_gpu": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense, 1),
-                       "step_frac_of_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
+                       "step_frac_of_bf16_mfma_peak": round(value / world * TFLOP_PER_CLIP[a.workload] * rows_run / rows_dense / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": (f"gemm_mxfp8 kernel (256x256x128 tile, 4 waves x 128x128, v_mfma_scale_f32_16x16x128_f8f6f4) + the re-cut launch of its partial "
                                                      f"last round on the gate/up projection [{pM}x{pK}]x[{pN}x{pK}]^T, per vlb_gemm_mxfp8 call; peak = dense fp8 MFMA" if a.fp8 else
                                                      "gemm_w4_kernel (256x256x64 tile, 4 waves x 128x128) + the split-K launches of its partial last wave "

@@ -30,12 +30,20 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libvlb.so is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file
+ * are the ONLY dynamic symbols it exports (no mangled helpers, no kernel launch stubs). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VLB_OK 0
 #define VLB_ERR_INVALID (-1) /* bad shape / alignment / argument */
 #define VLB_ERR_LAUNCH (-2)  /* HIP launch error */
 
-#define VLB_ABI_VERSION 1
+/* 2 (round 4): symbols are hidden unless declared here; vlb_gemm_masked_pair_swiglu_bwd requires 16-byte-aligned
+ * [gate | up] rows (round 3, also checked by VLB_REQUIRE at the call); entry points added since 1 are listed in
+ * INTEGRATION.md.  A binder checks `vlb_abi_version() == VLB_ABI_VERSION`. */
+#define VLB_ABI_VERSION 2
 
 /* epilogue activations for vlb_gemm_bf16 / vlb_layernorm_fwd */
 #define VLB_ACT_NONE 0
@@ -440,6 +448,9 @@ int vlb_profile_marker(void* stream);
 int vlb_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int vlb_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -135,7 +135,7 @@ def _load():
             raise ImportError(f"libvlb.so does not export {name}: rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
-    if lib.vlb_abi_version() != 1:
+    if lib.vlb_abi_version() != 2:
         raise ImportError("libvlb.so ABI version mismatch")
     return lib
 

@@ -13,10 +13,11 @@ import re
 
 import yaml
 
-# Lightning `_target_`s of the reference's YAML.  With Lightning installed they are instantiated as written (VLBLitModule is a
-# LightningModule then and bridges its explicit backward to the automatic-optimisation loop, litmodule._ExplicitLoss);
-# without it - this container, the GPU boxes - or with VLB_TRAINER=builtin they go to the built-in runner, which honours
-# the same keys.
+# Lightning `_target_`s of the reference's YAML.  By default they go to the built-in runner (phantom_vlb_amd.trainer), which
+# honours the same keys and is the loop every measurement and the data-parallel path use.  VLB_TRAINER=lightning opts in to
+# the real `lightning.pytorch` objects (VLBLitModule is a LightningModule whenever Lightning is importable and bridges its
+# explicit backward to the automatic-optimisation loop, litmodule._ExplicitLoss; single device only, checked in
+# on_fit_start).  The bridge has only ever run against tests/fake_lightning.py - the real package is not installed here.
 ROUTED_TARGETS = {
     "lightning.pytorch.Trainer": "phantom_vlb_amd.trainer.Trainer",
     "lightning.pytorch.loggers.CSVLogger": "phantom_vlb_amd.trainer.CSVLogger",
@@ -26,18 +27,15 @@ ROUTED_TARGETS = {
 
 
 def use_builtin_trainer() -> bool:
-    """True when the YAML's Lightning targets must be served by phantom_vlb_amd.trainer: Lightning is not importable, or
-    VLB_TRAINER=builtin asks for it (VLB_TRAINER=lightning insists on the real one and fails loudly without it)."""
-    want = os.environ.get("VLB_TRAINER", "auto")
-    if want == "builtin":
+    """True when the YAML's Lightning targets are served by phantom_vlb_amd.trainer: always, unless VLB_TRAINER=lightning
+    asks for the real package (and then its absence is an ImportError, not a silent fallback)."""
+    want = os.environ.get("VLB_TRAINER", "builtin")
+    if want in ("builtin", "auto", ""):
         return True
-    try:
-        import lightning.pytorch  # noqa: F401
-        return False
-    except Exception:
-        if want == "lightning":
-            raise
-        return True
+    if want != "lightning":
+        raise ValueError(f"VLB_TRAINER={want!r}: expected 'builtin' or 'lightning'")
+    import lightning.pytorch  # noqa: F401
+    return False
 
 
 def _merge(a: dict, b: dict) -> dict:

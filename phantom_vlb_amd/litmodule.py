@@ -417,10 +417,30 @@ class VLBLitModule(_Base):
         return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k not in keep else v) for k, v in batch.items()}
 
     def on_fit_start(self):
+        """Called by a Lightning ``Trainer.fit`` (never by the built-in runner).  What the bridge does not support is
+        refused here instead of producing wrong gradients: accumulation (every step overwrites the gradient buffers) and
+        anything but ONE device - Lightning's DDP / FSDP wrappers reduce autograd gradients, and the kernels' gradients
+        never flow through autograd (``_ExplicitLoss.backward`` returns None); multi-GPU runs use the built-in runner's
+        clip-sharded data parallelism (``torchrun ... train.py``, parallel.attach_data_parallel)."""
         tr = self.__dict__.get("_trainer") or self.__dict__.get("trainer")
         if getattr(tr, "accumulate_grad_batches", 1) not in (None, 1):
             raise ValueError("accumulate_grad_batches > 1 is not supported: every training_step overwrites the gradient buffers "
                              "(the reference's configs do not accumulate)")
+        world = getattr(tr, "world_size", 1) or 1
+        strategy = type(getattr(tr, "strategy", None)).__name__
+        if world > 1 or strategy not in ("NoneType", "SingleDeviceStrategy"):
+            raise ValueError(f"lightning.pytorch.Trainer with world_size={world}, strategy={strategy}: the Lightning bridge drives "
+                             "ONE device.  For N GPUs launch `torchrun --nproc-per-node N train.py ...` with VLB_TRAINER=builtin "
+                             "(the default): gradients are reduce-scattered by the package's own data-parallel step")
+
+    def on_save_checkpoint(self, checkpoint: dict) -> None:
+        """Lightning hook: the counter-based dropout state (head step, LoRA step) next to ``state_dict`` /
+        ``optimizer_states`` (VlbAdamW.state_dict carries moments, step count and the full fine-tune's backbone masters)."""
+        checkpoint["vlb_rng"] = self.rng_state()
+
+    def on_load_checkpoint(self, checkpoint: dict) -> None:
+        if "vlb_rng" in checkpoint:
+            self.set_rng_state(checkpoint["vlb_rng"])
 
     def state_dict(self, *args, **kwargs):
         """Trainables only, upstream / peft names (what a Lightning ModelCheckpoint stores for this module; the reference saves

@@ -71,6 +71,46 @@ class VlbAdamW(torch.optim.Optimizer):
         else:
             getattr(f, name).copy_(full)
 
+    # ------------------------------------------------------------------ checkpoint surface (torch.optim.Optimizer)
+    def state_dict(self):
+        """``torch.optim`` layout (``state`` / ``param_groups``) plus ``vlb``: the bias-correction step count and, per flat
+        store, both fp32 Adam moments (gathered under data parallelism) - and for the stores whose weights are NOT in the
+        module's ``state_dict()`` (index >= 1: the full fine-tune's backbone in kernel layouts) the fp32 masters too.  This
+        is what a Lightning ``ModelCheckpoint`` stores under ``optimizer_states``; the built-in runner's own checkpoint
+        (trainer.trainable_state) carries the same tensors."""
+        sd = super().state_dict()
+        stores = []
+        for i in range(len(self.flats)):
+            st = {"m": self.full_state("m", i).detach().cpu().clone(), "v": self.full_state("v", i).detach().cpu().clone()}
+            if i >= 1:
+                st["master"] = self.full_state("master", i).detach().cpu().clone()
+            stores.append(st)
+        sd["vlb"] = {"step_count": self.step_count, "stores": stores}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        vlb = state_dict.pop("vlb", None)
+        super().load_state_dict(state_dict)
+        if vlb is None:
+            raise KeyError("VlbAdamW.load_state_dict: no 'vlb' entry (moments / step count) - not a checkpoint of this optimiser")
+        if len(vlb["stores"]) != len(self.flats):
+            raise ValueError(f"checkpoint holds {len(vlb['stores'])} flat stores, this optimiser {len(self.flats)}")
+        self.step_count = int(vlb["step_count"])
+        for i, st in enumerate(vlb["stores"]):
+            f = self.flats[i]
+            if i == 0:
+                self.load_full_state("master", f.master, 0)       # the module's load_state_dict restored the masters
+            else:
+                self.load_full_state("master", st["master"], i)
+                chunk = 1 << 28
+                for a in range(0, f.numel, chunk):
+                    f.compute[a:a + chunk].copy_(f.master[a:a + chunk])
+            self.load_full_state("m", st["m"], i)
+            self.load_full_state("v", st["v"], i)
+        for fn in self.post_step:
+            fn()                      # derived layouts (LoRA A^T / B pads, W^T copies) from the restored weights
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

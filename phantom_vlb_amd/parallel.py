@@ -232,17 +232,27 @@ def attach_data_parallel(module, optimizer, group=None, comm=None, force_collect
     return state
 
 
-_direct_comms = {}
+_direct_comms = []          # [(live ProcessGroup object, DirectComm)]: identity-keyed, so a communicator never outlives its job
 
 
 def make_comm(group=None):
     """VLB_COMM=direct selects libvlb's own RCCL schedules (vlb_comm_*); default: torch.distributed.  One DirectComm (one
-    RCCL communicator, one issue order) per process group: the gradient exchange and the frozen-layer gathers share it."""
-    if os.environ.get("VLB_COMM", "torch") == "direct" and dist.is_initialized() and dist.get_backend(group) == "nccl":
+    RCCL communicator, one issue order) per process group: the gradient exchange and the frozen-layer gathers share it.
+    The cache is keyed by the live ProcessGroup OBJECT (``None`` = the current default group): after
+    ``destroy_process_group()`` + a new ``init_process_group()`` the default group is a new object and gets a new
+    communicator instead of one bootstrapped by the dead job."""
+    if not dist.is_initialized():
+        _direct_comms.clear()
+        return TorchComm(group)
+    if os.environ.get("VLB_COMM", "torch") == "direct" and dist.get_backend(group) == "nccl":
         from .parallel_native import DirectComm
-        if group not in _direct_comms:
-            _direct_comms[group] = DirectComm(group)
-        return _direct_comms[group]
+        pg = dist.group.WORLD if group is None else group
+        for live, comm in _direct_comms:
+            if live is pg:
+                return comm
+        comm = DirectComm(group)
+        _direct_comms.append((pg, comm))
+        return comm
     return TorchComm(group)
 
 

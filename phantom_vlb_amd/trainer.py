@@ -88,9 +88,17 @@ class TrainableCheckpoint:
     """ModelCheckpoint(monitor="val/brain_loss", mode="min", save_last=True) for the TRAINABLE tensors only
     (head + LoRA) - the reference saves the whole frozen 7B each time and notes the TODO (train.py:21-27,60)."""
 
-    def __init__(self, dirpath, monitor="val/brain_loss", mode="min", save_last=True, filename="best_brainloss", **kw):
+    def __init__(self, dirpath, monitor="val/brain_loss", mode="min", save_last=True, filename="best_brainloss_{epoch}-{step}",
+                 save_top_k=1, **kw):
         self.dirpath, self.monitor, self.mode, self.save_last, self.filename = dirpath, monitor, mode, save_last, filename
-        self.best = None
+        self.save_top_k = save_top_k
+        self.best, self.best_model_path = None, ""
+
+    def format_checkpoint_name(self, epoch: int, step: int) -> str:
+        """Lightning's naming (ModelCheckpoint.format_checkpoint_name with auto_insert_metric_name, its default): the
+        reference's ``filename="best_brainloss_{epoch}-{step}"`` (train.py:24) becomes ``best_brainloss_epoch=3-step=120.ckpt``."""
+        name = self.filename.replace("{epoch}", f"epoch={epoch}").replace("{step}", f"step={step}")
+        return os.path.join(self.dirpath, f"{name}.ckpt")
 
     def save(self, module, path, step):
         writer = int(os.environ.get("RANK", "0")) == 0
@@ -108,7 +116,11 @@ class TrainableCheckpoint:
         better = self.best is None or (val < self.best if self.mode == "min" else val > self.best)
         if better:
             self.best = val
-            self.save(module, os.path.join(self.dirpath, f"{self.filename}.ckpt"), trainer.global_step)
+            path = self.format_checkpoint_name(getattr(trainer, "current_epoch", 0), trainer.global_step)
+            self.save(module, path, trainer.global_step)
+            old, self.best_model_path = self.best_model_path, path
+            if self.save_top_k == 1 and old and old != path and os.path.exists(old) and int(os.environ.get("RANK", "0")) == 0:
+                os.remove(old)          # save_top_k=1 (Lightning's default): the previous best goes
         if self.save_last:
             self.save(module, os.path.join(self.dirpath, "last.ckpt"), trainer.global_step)
 
@@ -170,7 +182,7 @@ class Trainer:
         self.loggers = [lg for lg in (logger if isinstance(logger, (list, tuple)) else [logger]) if lg is not None]
         self.callbacks = list(callbacks or [])
         self.limit_val_batches = limit_val_batches
-        self.global_step = 0
+        self.global_step, self.current_epoch = 0, 0
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         want = devices if isinstance(devices, int) else (len(devices) if isinstance(devices, (list, tuple)) else 1)
@@ -256,6 +268,7 @@ class Trainer:
         t0 = time.time()
         start_epoch, skip = divmod(self.global_step, max(n_batches, 1)) if ckpt_path else (0, 0)
         for epoch in range(start_epoch, self.max_epochs):
+            self.current_epoch = epoch
             if hasattr(train_loader.sampler, "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)
             self._cb("on_train_epoch_start", model)

@@ -28,9 +28,9 @@ def _run_with_fake_lightning(tmp_path, code, env_extra=None):
 
 def test_with_lightning_installed_the_yaml_targets_and_base_classes_are_lightnings(tmp_path):
     """Reference train.py:41-56 instantiates `lightning.pytorch.Trainer` from the YAML and hands it VLBLitModule /
-    VLBDataModule / LogValAccuracyCallback.  With a `lightning` package importable those targets are instantiated as
-    written and the three classes subclass Lightning's bases (Trainer.fit type-checks them); VLB_TRAINER=builtin still
-    selects the built-in runner."""
+    VLBDataModule / LogValAccuracyCallback.  With a `lightning` package importable the three classes subclass Lightning's
+    bases (Trainer.fit type-checks them) and VLB_TRAINER=lightning instantiates those targets as written; the default
+    (and VLB_TRAINER=builtin) is the built-in runner - the Lightning bridge is opt-in."""
     code = """
         import os, sys
         import lightning.pytorch as lp
@@ -44,15 +44,16 @@ def test_with_lightning_installed_the_yaml_targets_and_base_classes_are_lightnin
         cfg = C.load_config("config", ["experiment=VLB_vllama2_friends_lora", "subject=sub-01", "output_dir=/tmp/x"])
         assert cfg["trainer"]["_target_"] == "lightning.pytorch.Trainer"          # the reference's YAML, unchanged
         tr = C.instantiate(cfg["trainer"], logger=[], callbacks=[])
-        want_builtin = os.environ.get("VLB_TRAINER") == "builtin"
+        want_builtin = os.environ.get("VLB_TRAINER", "builtin") == "builtin"
         assert (type(tr) is T.Trainer) == want_builtin and (type(tr) is lp.Trainer) == (not want_builtin)
         assert tr.gradient_clip_val == 1
         lg = C.instantiate(cfg["cvs_logger"])
         assert (type(lg) is T.CSVLogger) == want_builtin
         print("OK", type(tr).__module__)
     """
-    assert "OK lightning.pytorch" in _run_with_fake_lightning(tmp_path, code)
+    assert "OK lightning.pytorch" in _run_with_fake_lightning(tmp_path, code, {"VLB_TRAINER": "lightning"})
     assert "OK phantom_vlb_amd.trainer" in _run_with_fake_lightning(tmp_path, code, {"VLB_TRAINER": "builtin"})
+    assert "OK phantom_vlb_amd.trainer" in _run_with_fake_lightning(tmp_path, code)      # the default is the built-in runner
 
 
 def test_without_lightning_the_builtin_runner_serves_the_yaml(tmp_path):

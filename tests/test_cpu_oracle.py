@@ -148,11 +148,13 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
     # the product library exports exactly the declared ABI: no kernel-variant / ablation switches (tools build only)
     import subprocess
+    # (-fvisibility=hidden + the header's visibility push: no mangled helper, no kernel launch stub, no data symbol either)
     exported = {ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
-                                                        text=True, check=True).stdout.splitlines() if " T vlb_" in ln}
+                                                        text=True, check=True).stdout.splitlines()
+                if ln.split()[-2] in "TtDdBbRrWwVv" and not ln.split()[-1].startswith(("_init", "_fini", "__hip_"))}
     assert exported == set(names), exported ^ set(names)
     assert _lib.IS_PRODUCT_LIB
-    assert _lib.lib.vlb_abi_version() == 1
+    assert _lib.lib.vlb_abi_version() == 2
     assert _lib.lib.vlb_gemm_kernel_choice(10240, 4096, 4096, 0) == 1
     assert _lib.lib.vlb_gemm_kernel_choice(5, 2048, 4096, 0) == 0
     assert _lib.lib.vlb_head_partial_rows(2048) == 64

@@ -32,8 +32,12 @@ def test_train_py_mini_experiment(tmp_path):
     val = [float(x["val/brain_loss"]) for x in rows if x.get("val/brain_loss")]
     assert len(train) >= 6 and len(val) >= 2
     assert train[-1] < train[0]                      # the head learns on the fixed synthetic clips
-    for f in ("best_brainloss.ckpt", "last.ckpt", "final.ckpt"):
+    for f in ("last.ckpt", "final.ckpt"):
         assert (out / f).exists()
+    # reference train.py:24 filename="best_brainloss_{epoch}-{step}" as Lightning formats it; save_top_k=1 keeps ONE best
+    import re
+    best = [f for f in os.listdir(out) if f.startswith("best_brainloss_")]
+    assert len(best) == 1 and re.fullmatch(r"best_brainloss_epoch=\d+-step=\d+\.ckpt", best[0]), best
     st = torch.load(out / "final.ckpt", map_location="cpu")
     assert set(st["state_dict"]) == {"layer_norm1.weight", "layer_norm1.bias", "layer_norm2.weight", "layer_norm2.bias",
                                      "ridge_layer.linear.weight", "ridge_layer.linear.bias"}      # trainables only
@@ -252,3 +256,56 @@ print("BRIDGE_OK")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, ROOT, os.path.join(ROOT, "oracle")]))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0 and "BRIDGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_lightning_checkpoint_resume_is_exact_and_multi_device_is_refused(dev, tmp_path):
+    """on the Lightning path ModelCheckpoint stores `module.state_dict()` + `optimizer.state_dict()` +
+    `on_save_checkpoint`.  VlbAdamW.state_dict carries the Adam moments and the bias-correction step, the module's hook the
+    dropout counters: 2 steps + save + resume in a NEW module + 2 steps == 4 straight steps, bit for bit (LoRA + both
+    dropouts on).  And a Lightning Trainer with more than one device is refused in on_fit_start (DDP would step on
+    unreduced gradients: the kernels' gradients never flow through autograd)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_lightning
+    root = fake_lightning.write(tmp_path / "site")
+    code = r'''
+import sys, torch
+import lightning.pytorch as lp
+from src.litmodule import VLBLitModule, VLBLitModuleConfig
+from src.datamodule import VLBDataModule, VLBDataModuleConfig
+
+def cfg():
+    return VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=True, lora_r=16, lora_alpha=32, lora_dropout=0.1,
+                              dropout_rate=0.1, num_target=128, l2_lambda=1e-3, lr=1e-3, betas=[0.9, 0.999], eps=1e-8, weight_decay=1e-2,
+                              lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini")
+
+def dm():
+    return VLBDataModule(VLBDataModuleConfig(lazyload_path="synthetic:3x4", subject="sub-01", seasons=["s1"], delay=3, window=3,
+                                             random_state=1234, shuffle_val_data=False, batch_size=2, geometry="mini", num_target=128))
+
+def tr(**kw):
+    return lp.Trainer(precision="bf16-mixed", gradient_clip_val=1, max_epochs=3, **kw)
+
+path = sys.argv[1]
+a = VLBLitModule(cfg()); ta = tr(max_steps=4); ta.fit(model=a, datamodule=dm())
+b = VLBLitModule(cfg()); tb = tr(max_steps=2); tb.fit(model=b, datamodule=dm()); tb.save_checkpoint(path)
+ck = torch.load(path, map_location="cpu", weights_only=False)
+v = ck["optimizer_states"][0]["vlb"]
+assert v["step_count"] == 2 and float(v["stores"][0]["m"].abs().max()) > 0 and float(v["stores"][0]["v"].abs().max()) > 0
+assert ck["vlb_rng"]["head_step"] == 2 and any(".lora_B." in k for k in ck["state_dict"])
+c = VLBLitModule(cfg()); tc = tr(max_steps=4); tc.fit(model=c, datamodule=dm(), ckpt_path=path)
+assert tc.global_step == 4 and c.optimizer.step_count == 4
+assert torch.equal(a.flat.master, c.flat.master) and torch.equal(a.flat.compute, c.flat.compute), "resumed parameters differ"
+assert torch.equal(a.flat.m, c.flat.m) and torch.equal(a.flat.v, c.flat.v), "resumed moments differ"
+assert a.optimizer.param_groups[0]["lr"] == c.optimizer.param_groups[0]["lr"]
+assert not torch.equal(a.flat.master, b.flat.master)
+try:
+    tr(max_steps=1, devices=2).fit(model=VLBLitModule(cfg()), datamodule=dm())
+    raise SystemExit("a 2-device Lightning Trainer was accepted")
+except ValueError as e:
+    assert "ONE device" in str(e)
+print("RESUME_OK")
+'''
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, ROOT, os.path.join(ROOT, "oracle")]), VLB_TRAINER="lightning")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "lightning.ckpt")], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0 and "RESUME_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -4,7 +4,8 @@ north_star: "loss matching CPU reference to 1e-3 rel".  The mini model proves th
 VideoLLaMA2-7B geometry runs - 23 executed ViT-L/14-336 layers, the full STC connector, the splice and all 32 Mistral decoder
 layers at d=4096 / ff=14336 / S=2048 - on ONE synthetic clip, and the loss and the predicted BOLD are compared with the fp32
 oracle (oracle/vlb_oracle.py: training_loss, reference src/litmodule/videollama2_vlb_litmodule.py:229-306) fed the SAME
-bf16-valued weights: frozen backbone (configs[1]) and LoRA r=16 with B != 0, dropout off (configs[2]).  This is where bf16
+bf16-valued weights: frozen backbone (configs[1]) and LoRA r=16 with B != 0, dropout off (configs[2]) - for the latter also the
+GRADIENTS the optimiser consumes (head + the 14 adapter matrices of layers 0 / 15 / 31) against the oracle's loss.backward().  This is where bf16
 rounding accumulates through 23 + 32 residual layers.  Plus one whole-model configs[4] step (full-parameter fine-tune, 65,536-voxel
 head, bf16 and MX-fp8 GEMMs) so the driver's GPU run exercises it.
 
@@ -67,7 +68,10 @@ def _state_dict_7b(g, dev, seed, lora):
 
 def test_7b_full_depth_loss_and_prediction_vs_oracle(dev):
     import vlb_oracle as O
+    from phantom_vlb_amd.head import HEAD_PARAMS
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.lora import GROUPS
+    GRAD_LAYERS = (0, 15, 31)
     g = O.geometry_7b(num_target=2048, lora_r=16, lora_alpha=32)
     assert (g.vit_layers_run, g.layers, g.vis_tokens, g.max_len) == (23, 32, 1183, 2048)
     _progress("full-depth parity: generating 7.3 B bf16 weights on the device")
@@ -91,6 +95,14 @@ def test_7b_full_depth_loss_and_prediction_vs_oracle(dev):
     pred_lora = m.head.pred.float().cpu().clone()
     gsq = sum(float(t.grad.float().pow(2).sum()) for _, t in m.trainable_named_parameters())
     assert gsq > 0 and gsq == gsq                          # finite, non-zero gradients through all 32 layers
+    # what the optimiser consumes: head gradients and the 14 adapter gradients of the first, a middle and the last layer
+    # (reference :113-120, 259-306: peft's A / B are the only backbone tensors with requires_grad)
+    grad_names = list(HEAD_PARAMS) + [f"model.layers.{i}.{t}.lora_{ab}.weight" for i in GRAD_LAYERS for _, ts in GROUPS for t in ts
+                                      for ab in "AB"]
+    dev_grads = {}
+    for n in grad_names:
+        gt = m.head.grads[n] if n in m.head.grads else m.lora.grads[n]
+        dev_grads[n] = (gt.t() if "lora_B" in n else gt).float().cpu().clone()
     val_lora = float(m.validation_step(dbatch)["loss"])
     lora, m.lora = m.lora, None
     try:
@@ -114,11 +126,34 @@ def test_7b_full_depth_loss_and_prediction_vs_oracle(dev):
                                 g.ds_grid ** 2).to(BF).float()
         y = batch["timeseries"].to(BF).float()
         ref = {}
-        for tag, pp in (("frozen", p_frozen), ("lora", p)):
-            hid = O.mistral_decoder(pp, emb, km, g)
-            pred, l2, _ = O.brain_head(pp, hid, wm, g)
-            ref[tag] = (float(F.mse_loss(pred, y) + l2), pred)
-            _progress(f"oracle: 32 decoder layers + head ({tag}) done, loss {ref[tag][0]:.6f}")
+        hid = O.mistral_decoder(p_frozen, emb, km, g)
+        pred, l2, _ = O.brain_head(p_frozen, hid, wm, g)
+        ref["frozen"] = (float(F.mse_loss(pred, y) + l2), pred)
+        _progress(f"oracle: 32 decoder layers + head (frozen) done, loss {ref['frozen'][0]:.6f}")
+        del hid
+    # the LoRA pass WITH autograd (host memory: ~1.5 GB of saved fp32 activations per layer; the GPU box has > 200 GB): the same
+    # loss.backward() the reference's Trainer runs, for the tensors listed in grad_names
+    for n in grad_names:
+        p[n].requires_grad_(True)
+    hid = O.mistral_decoder(p, emb, km, g)
+    pred, l2, _ = O.brain_head(p, hid, wm, g)
+    loss = F.mse_loss(pred, y) + l2
+    ref["lora"] = (float(loss), pred.detach())
+    _progress(f"oracle: 32 decoder layers + head (lora, autograd on) done, loss {ref['lora'][0]:.6f}")
+    loss.backward()
+    _progress("oracle: backward through 32 decoder layers done")
+    del hid, loss
+    worst = {}
+    for n in grad_names:
+        a, b = dev_grads[n], p[n].grad
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        key = "head" if ".lora_" not in n else f"layer {n.split('.')[2]}"
+        w = worst.setdefault(key, [0.0, 1.0])
+        w[0], w[1] = max(w[0], err), min(w[1], cos)
+        assert err <= 5e-2 and cos >= 0.99, (n, err, cos)
+    _progress("gradients vs oracle autograd (worst max-error / max, worst cosine): " +
+              "; ".join(f"{k} {v[0]:.2e} / {v[1]:.5f}" for k, v in worst.items()))
     assert rel_err(vid_dev.view(1, g.vis_tokens, g.dim), vid) < 6e-2           # 23 ViT layers + 8 RegStage blocks in bf16
     e_f = abs(loss_frozen - ref["frozen"][0]) / ref["frozen"][0]
     e_l = abs(loss_lora - ref["lora"][0]) / ref["lora"][0]
@@ -134,7 +169,7 @@ def test_7b_full_depth_loss_and_prediction_vs_oracle(dev):
 def test_configs4_whole_model_step_bf16_and_fp8(dev):
     """configs[4]'s model side as ONE whole step on the GPU: full-parameter fine-tune of the 7B geometry (everything but the
     vision tower trains), 65,536-voxel head, B = 1 - bf16 GEMMs, then the same weights and clip with the decoder GEMMs on the
-    MX-fp8 MFMA path: finite non-zero gradients for every trained tensor group, fp8 loss within 2 % of bf16, gradient cosines by depth,
+    MX-fp8 MFMA path: finite non-zero gradients for every trained tensor group, fp8 loss within 1e-3 of bf16, gradient cosines by depth,
     and an optimiser step that moves the weights."""
     from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
     from phantom_vlb_amd.synthetic import synthetic_batch
@@ -165,7 +200,7 @@ def test_configs4_whole_model_step_bf16_and_fp8(dev):
     loss8 = float(m.training_step(batch))
     g8 = f.grad
     assert torch.isfinite(g8.float()).all()
-    assert abs(loss8 - loss16) <= 2e-2 * abs(loss16), (loss8, loss16)
+    assert abs(loss8 - loss16) <= 1e-3 * abs(loss16), (loss8, loss16)      # measured 7e-5
     # gradient agreement bf16 vs MX-fp8 (e4m3 operands: ~4e-2 of the output rms per K = 4096 GEMM, tests/test_gpu_fp8.py), by
     # depth: the error of the backward signal accumulates through the fp8 dgrad GEMMs of the layers above
     cos = {}

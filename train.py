@@ -1,11 +1,12 @@
 """Drop-in for the reference's train.py (train.py:1-70): same CLI
 ``python train.py experiment=<name> subject=<sub-XX>`` and the same YAML keys.
 
-The YAML is read by the built-in Hydra-subset loader (phantom_vlb_amd.config).  With Lightning installed,
-``_target_: lightning.pytorch.Trainer`` and the callbacks are the real ones (VLBLitModule / VLBDataModule /
-LogValAccuracyCallback then subclass the Lightning base classes, like the reference's; the reference's own unchanged
-train.py drives them the same way); without it - or with VLB_TRAINER=builtin - the built-in fit loop
-(phantom_vlb_amd.trainer) honours the same keys.  Comet logging is optional: without ``comet_ml`` or
+The YAML is read by the built-in Hydra-subset loader (phantom_vlb_amd.config).  ``_target_: lightning.pytorch.Trainer`` and
+the callbacks are served by the built-in fit loop (phantom_vlb_amd.trainer), which honours the same keys -
+the default, and the loop behind every measured number and the multi-GPU path.  VLB_TRAINER=lightning opts in to the real
+Lightning objects (VLBLitModule / VLBDataModule / LogValAccuracyCallback subclass the Lightning base classes whenever the
+package is importable, so the reference's own unchanged train.py can drive them too): ONE device, exercised only against
+tests/fake_lightning.py so far.  Comet logging is optional: without ``comet_ml`` or
 credentials only the CSV logger is attached.
 """
 from __future__ import annotations
@@ -34,7 +35,7 @@ def train(config: dict) -> None:
     random.seed(seed)
 
     callbacks = [
-        TrainableCheckpoint(monitor="val/brain_loss", filename="best_brainloss", mode="min",
+        TrainableCheckpoint(monitor="val/brain_loss", filename="best_brainloss_{epoch}-{step}", mode="min",     # train.py:21-27
                             dirpath=config["output_dir"], save_last=True),
         LearningRateMonitor(logging_interval="epoch"),
         LogValAccuracyCallback(),
