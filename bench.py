@@ -265,6 +265,29 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms, launches, (pM, pN, pK) = probe.result()
+    # ---- the whole long-K GEMM family (every four-wave launch: plain, gate/up + SwiGLU, masked-pair dgrads, with their tail
+    # launches), from event pairs around each call in TWO EXTRA steps after the timed region (the pairs cost ~2 us per GEMM,
+    # so they stay out of `value`); vision prefetch off for these so no side-stream kernel runs under a timed call
+    fam_steps = 2 if a.geometry == "7b" and not a.fp8 else 0
+    family = None
+    if fam_steps and rank == 0 or (fam_steps and use_dist):
+        fprobe = ops.enable_gemm_probe(N=2 * g.ff, K=g.dim, family=True)
+        was = pipelined
+        pipelined = False
+        for _ in range(fam_steps):
+            step()
+        pipelined = was
+        ops.disable_gemm_probe()
+        fam = fprobe.family_result()
+        tot_ms = sum(v[1] for v in fam.values())
+        tot_tf = sum(v[2] for v in fam.values())
+        family = {"what": "every bf16 GEMM call with K + K2 >= 4096 (the four-wave kernels incl. 192-row, masked-pair and split-K / re-cut "
+                          "tail launches), HIP-event pairs around each call in %d extra untimed steps, one stream" % fam_steps,
+                  "ms_per_step": round(tot_ms / fam_steps, 2), "tflop_per_step": round(tot_tf / fam_steps, 2),
+                  "tflops": round(tot_tf / (tot_ms * 1e-3), 1) if tot_ms else 0.0,
+                  "frac_of_bf16_peak": round(tot_tf / (tot_ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if tot_ms else 0.0,
+                  "by_kind": {k: {"calls_per_step": v[0] // fam_steps, "ms_per_step": round(v[1] / fam_steps, 2),
+                                  "tflops": round(v[2] / (v[1] * 1e-3), 1)} for k, v in sorted(fam.items())}}
     # the recorded collections are per call KIND: LoRA / frozen calls under the bare shape, the fp8 call under "fp8:", the plain
     # bf16 call of the full fine-tune (no collection on record) under "full:"
     traffic, traffic_src = gateup_traffic((pM, pN, pK), "fp8:" if a.fp8 else "full:" if full else "")
@@ -315,6 +338,7 @@ def main():
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 2.0 * pM * pN:.3e} (A + W + C [M,N] bf16)" if full else
                             f"algorithmic {2.0 * (pM * pK + pN * pK) + 1.0 * pM * pN:.3e} (A + W + SwiGLU-fused C [M,N/2] bf16)"),
                          "flops_per_launch": flops_launch, "avg_launch_ms": round(kern_ms, 4), "launches_timed": launches},
+            "gemm_family": family,
         }
         if world == 1 and not a.no_cpu_baseline and a.geometry == "7b" and not full:
             out["cpu_baseline"] = cpu_baseline(cfg.num_target, lora)

@@ -1145,6 +1145,222 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #undef W4_EPILOGUE
 }
 
+#ifdef VLB_TOOLS
+// ------------------------------------------------------------------------------------------------
+// W-direct variant of the four-wave 256x256x64 tile (gemm_wd_kernel).  TOOLS BUILD ONLY: built in round 4 because the
+// ablations of gemm_w4_kernel pointed at the LDS-DMA issue, measured 4-9 % SLOWER than gemm_w4_kernel on every shape it serves
+// (interleaved same-process A/B, outputs bit-identical; DESIGN.md 5.1 has the table and the instruction-level probe that
+// explains it: a fragment-shaped global load - 16 rows x 64 B - costs the vector memory path ~4x a line-shaped one per byte).
+// Kept as the record of that experiment and as the A/B partner of tools/ab_gemm_rowsplit.py (VLB_AB=wd).
+//
+// What the ablations of gemm_w4_kernel say: with one wave per SIMD the LDS-DMA ISSUE is the largest cost
+// of the K loop (16 pieces per wave per K-tile, 60-185 issue cycles each, during which the in-order wave issues no MFMA).
+// Here only A goes through LDS: the four waves sit 1 (M) x 4 (N), wave w owns output columns [64w, 64w+64) of ALL 256
+// rows (16 x 4 accumulator tiles = the same 256 AGPRs), so
+//   * a wave's W fragments are its own (no other wave needs them): they come straight from global / L2 into REGISTERS,
+//     one K-tile ahead - 8 plain global_load_dwordx4 per wave per K-tile (16 rows x 64 B each: lane (fr, fq) fetches the
+//     16 bytes of W row fr that it feeds to the MFMA as k-group fq), no LDS write, no LDS read, no barrier dependence;
+//   * A (the operand all four waves share) is staged by LDS-DMA as before: 32 pieces of 1 KiB per K-tile = 8 per wave
+//     (half the pieces of the 2 x 2 layout), 32 KB per stage, two stages;
+//   * every wave reads all 16 A fragments of a k-step from LDS: 32 ds_read_b128 per wave per K-tile, as many as before,
+//     against an LDS image that now takes half the DMA write traffic.
+// Per K-tile and wave: 128 MFMA, 32 ds_read_b128, 8 LDS-DMA pieces, 8 global loads, 1 barrier, two COUNTED vmcnt waits
+// (never 0 in the loop: W(t+1) is waited for with A(t+2)'s pieces still in flight and vice versa).
+//
+// Registers by hand.  The W double buffer lives in v[192:255]: buffer b, k-step ks, fragment j = v[192 + 16(2b+ks)... see
+// WD_WREG.  The loads and the MFMAs that read them name those registers literally (the compiler-allocated prototype of
+// round 2 died in register allocation: asm outputs that are written asynchronously cannot be expressed as operands); every
+// asm statement that writes them lists all 64 as clobbers, so the compiler keeps nothing of its own there across any of
+// them, and tools/audit_gemm_isa.py proves on the generated ISA that no compiler-issued instruction touches v192+ between
+// the first W load and the end of the K loop.  Accumulators are tied AGPR tuples as in gemm_w4_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+#define WD_CLOBBER "v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255"
+// W register quad of buffer b (tile parity), k-step ks, fragment j
+constexpr int WD_WREG(int b, int ks, int j) { return 192 + ((b * 2 + ks) * 4 + j) * 4; }
+template <int R, int OFF>
+__device__ __forceinline__ void wd_load_w(uint32_t voff, const char* sbase) {
+  asm volatile("global_load_dwordx4 v[%c2:%c3], %0, %1 offset:%c4" ::"v"(voff), "s"(sbase), "i"(R), "i"(R + 3), "i"(OFF) : "memory", WD_CLOBBER);
+}
+template <int R>
+__device__ __forceinline__ void wd_mfma(f32x4& c, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, v[%c2:%c3], %1, %0" : "+a"(c) : "v"(__builtin_bit_cast(i32x4_t, a)), "i"(R), "i"(R + 3));
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_wd_kernel(GemmArgs p) {
+  constexpr int MT = 16, NT = 4, BM = 256, BN = 256, TN = 16 * NT;
+  constexpr int STAGE = BM * ROW_BYTES;               // one A tile: 32 KB
+  constexpr int A_LD = BM / 32;                       // LDS-DMA pieces per wave per K-tile
+  constexpr int W_LD = 2 * NT;                        // W loads per wave per K-tile
+  constexpr int LAST_A = MT / 2;                      // group in which the double-slotted last A fragment is fetched
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  asm volatile("" ::: WD_CLOBBER);                    // v[192:255] are part of this kernel's register budget from here on
+
+  int m0, n0;
+  map_tile(p, BM, BN, m0, n0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // A staging as in gemm_w4_kernel: piece i of this wave fills LDS rows [i*32 + wave*8, +8), swizzle on the source address
+  const int srow = (lane >> 3), sslot = lane & 7;
+  const int r0 = wave * 8 + srow;
+  const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
+  const int rowA = m0 + r0;
+  const int rowW = n0 + wave * TN + fr;               // W row of this lane in fragment 0 (fragment j: + 16 j)
+  const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
+
+  // two cursors: A's LDS-DMA runs two K-tiles ahead of the MFMAs, W's register loads one
+  uint32_t offA[A_LD], offW[NT];
+  const char* curA; const char* curW;
+  auto set_a = [&](const bf16* A_, int lda_) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) offA[i] = ((uint32_t)min(rowA + 32 * i, p.M - 1) * (uint32_t)lda_ + (uint32_t)colb) * 2u;
+    curA = reinterpret_cast<const char*>(A_);
+  };
+  auto set_w = [&](const bf16* W_, int ldw_) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) offW[j] = ((uint32_t)(rowW + 16 * j) * (uint32_t)ldw_ + (uint32_t)(fq * 8)) * 2u;
+    curW = reinterpret_cast<const char*>(W_);
+  };
+  auto select_a = [&](int kt) { if (kt == 0) set_a(p.A, p.lda); else if (kt == nk1) set_a(p.A2, p.lda2); else curA += ROW_BYTES; };
+  auto select_w = [&](int kt) { if (kt == 0) set_w(p.W, p.ldw); else if (kt == nk1) set_w(p.W2, p.ldw2); else curW += ROW_BYTES; };
+  auto dma = [&](int buf, int i) { glds16(curA + offA[i], smem + buf * STAGE + wave * 8 * ROW_BYTES + i * 32 * ROW_BYTES); };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int a_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) a_off[ks] = lds_off(fr, ks * 4 + fq);
+  auto frag = [&](const char* sb, int off, int t) { return *reinterpret_cast<const bf16x8*>(sb + off + t * 16 * ROW_BYTES); };
+
+#define WD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WD_BARRIER() do { WD_FENCE(); __builtin_amdgcn_s_barrier(); WD_FENCE(); } while (0)
+
+  // prologue: A(0) -> stage 0, W(0) -> register buffer 0, A(1) -> stage 1
+  select_a(0);
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) dma(0, i);
+  select_w(0);
+  static_for<0, W_LD>([&](auto qc) {
+    constexpr int q = decltype(qc)::value, j = q >> 1, ks = q & 1;
+    wd_load_w<WD_WREG(0, ks, j), ks * 64>(offW[j], curW);
+  });
+  if (nk > 1) select_a(1);                            // (a single-tile K range re-fetches tile 0: same counted waits everywhere)
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) dma(1, i);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD) : "memory");        // A(0) and W(0) are in; A(1) may still fly
+  WD_BARRIER();
+
+  // A fragments are refreshed IN PLACE: af[i] is consumed by the 4 MFMAs of group i and refetched (next k-step) at the top
+  // of group i+1; the last one would be refetched right in front of the barrier that needs it complete, so it has two slots.
+  bf16x8 af[MT - 1], al[2];
+#pragma unroll
+  for (int i = 0; i < MT - 1; ++i) af[i] = frag(smem, a_off[0], i);
+  al[0] = frag(smem, a_off[0], MT - 1);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  WD_FENCE();
+
+  // One K-tile kt of parity PAR (= its LDS stage and its W register buffer).  ONE body serves every tile: past the end of
+  // the K range the cursors simply stop advancing, so the last tiles re-fetch the final K-tile's operands into buffers that
+  // nobody reads again (redundant loads of valid addresses instead of tail variants of a 128-MFMA body: with several
+  // variants inlined the register allocator no longer keeps the 64 accumulator tuples in place).
+  auto tile = [&](int kt, auto par_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    const char* sb = smem + PAR * STAGE;
+    const char* sn = smem + (PAR ^ 1) * STAGE;
+    if (kt + 1 < nk) select_w(kt + 1);
+    // ---------------- block 1: MFMA(k-step 0) || A reads of k-step 1 || W(kt+1) -> the other register buffer
+    static_for<0, MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i >= 1) af[i - 1] = frag(sb, a_off[1], i - 1);
+      if constexpr (i == LAST_A) al[1] = frag(sb, a_off[1], MT - 1);
+      if constexpr (i % 2 == 0) {
+        constexpr int q = i / 2, j = q >> 1, ks = q & 1;
+        wd_load_w<WD_WREG(PAR ^ 1, ks, j), ks * 64>(offW[j], curW);
+      }
+      static_for<0, NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (i == MT - 1) wd_mfma<WD_WREG(PAR, 0, j)>(acc[i][j], al[0]);
+        else wd_mfma<WD_WREG(PAR, 0, j)>(acc[i][j], af[i]);
+      });
+      WD_FENCE();
+    });
+    // this wave is done reading stage PAR (lgkmcnt); A(kt+1) has landed: only the W(kt+1) loads, issued after it, may fly
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_LD) : "memory");
+    WD_BARRIER();
+    if (kt + 2 < nk) select_a(kt + 2);
+    // ---------------- block 2: MFMA(k-step 1) || LDS-DMA of A(kt+2) into stage PAR || A reads of tile kt+1, k-step 0
+    static_for<0, MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i >= 1) af[i - 1] = frag(sn, a_off[0], i - 1);
+      if constexpr (i == LAST_A) al[0] = frag(sn, a_off[0], MT - 1);
+      if constexpr (i % 2 == 0) dma(PAR, i / 2);
+      static_for<0, NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (i == MT - 1) wd_mfma<WD_WREG(PAR, 1, j)>(acc[i][j], al[1]);
+        else wd_mfma<WD_WREG(PAR, 1, j)>(acc[i][j], af[i]);
+      });
+      WD_FENCE();
+    });
+    // next tile's first fragments are in; W(kt+1) has landed: only A(kt+2)'s pieces, issued after it, may fly
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD) : "memory");
+    asm volatile("s_nop 15" ::: "memory");      // XDL write -> (compiler-placed) VALU read of an accumulator on a loop exit edge
+    WD_FENCE();
+  };
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) { tile(kt, P0{}); tile(kt + 1, P1{}); }
+  if (kt < nk) tile(kt, P0{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant tail fetches (register and LDS destinations) are retired
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MT; ++i) asm volatile("" : "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]));
+#undef WD_FENCE
+#undef WD_BARRIER
+
+  // epilogues of gemm_w4_kernel with this kernel's wave block (rows m0.., columns n0 + 64 wave ..)
+  if (p.act == VLB_ACT_SWIGLU_PAIR) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + i * 16 + fr;
+      if (m >= p.M) continue;
+      store_swiglu8(p, acc[i][0], acc[i][1], acc[i][2], acc[i][3], m, (n0 + wave * TN) / 2 + fq * 4, fq);
+    }
+    return;
+  }
+#define WD_EPILOGUE(KIND)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                      \
+    const int m = m0 + i * 16 + fr;                                                                                     \
+    if (m >= p.M) continue;                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NT; j += 2)                                                                   \
+      w4_store_frag2<KIND>(p, acc[i][j], acc[i][j + 1], m, n0 + wave * TN + j * 16 + fq * 4, fq);                       \
+  }
+  const int kind = w4_epilogue_kind(p);
+  if (kind == EPI_PLAIN) { WD_EPILOGUE(EPI_PLAIN) return; }
+  if (kind == EPI_RESIDUAL) { WD_EPILOGUE(EPI_RESIDUAL) return; }
+  if (kind == EPI_SWIGLU_BWD) { WD_EPILOGUE(EPI_SWIGLU_BWD) return; }
+#define WD_EPILOGUE_ACT(ACT) WD_EPILOGUE(EPI_GENERIC + ACT)
+  VLB_DISPATCH_ACT(p.act, WD_EPILOGUE_ACT);
+#undef WD_EPILOGUE_ACT
+#undef WD_EPILOGUE
+}
+
+#endif  // VLB_TOOLS (W-direct experiment)
+
 // Second half of a split-K tail: block (tile, i) sums row-tile i of every wave's accumulators over the splits in
 // a fixed order (deterministic) and applies the four-wave kernel's epilogue with the same thread <-> element map.
 template <int MT, int NT>
@@ -1186,8 +1402,29 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
 int g_w4_rowsplit = 0;              // tools: 1 = every four-wave launch uses the row-split K loop (ABL bit 6)
 int g_w4_persist = 0;               // tools: 1 = whole-tile 256-column launches run as a persistent stream (ABL bit 7)
 #endif
+#ifdef VLB_TOOLS
+int g_wd = 0;                       // tools: 1 = whole 256x256-tile launches run on gemm_wd_kernel (A/B of the W-direct experiment)
+// whole 256x256 tiles, both operand pairs, every epilogue kind; no masked pair, no split-K (those launches keep gemm_w4_kernel)
+inline int launch_wd(GemmArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * 256 * ROW_BYTES;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) {
+    vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
+    return VLB_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(gemm_wd_kernel, dim3(a.grid), dim3(256), LDS, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+#endif
+
 template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
+#ifdef VLB_TOOLS
+  if constexpr (NT == 8 && ABL == 0 && MT == 8 && !MASKED && !SPLITK) {
+    if (g_wd && a.split_n == 1 && a.k_splits <= 1) return launch_wd(a, s);
+  }
+#endif
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
@@ -1672,6 +1909,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
 extern "C" void vlb_gemm_set_stagger(int ticks) { g_stagger = ticks; }
 extern "C" void vlb_gemm_set_rowsplit(int on) { g_w4_rowsplit = on; }
 extern "C" void vlb_gemm_set_persist(int on) { g_w4_persist = on; }
+extern "C" void vlb_gemm_set_wd(int on) { g_wd = on; }
 extern "C" void vlb_gemm_set_variant(int variant, int force_tile) {
   g_variant = variant & 0xff;     // 3 = default (auto)
   g_force_tile = force_tile;

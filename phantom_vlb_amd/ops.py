@@ -28,11 +28,16 @@ def _dev(t):
 
 
 class _GemmProbe:
-    """HIP-event pairs (on the launch stream) around every vlb_gemm_bf16 call of one (N,K) shape."""
+    """HIP-event pairs (on the launch stream) around every vlb_gemm_bf16 call of one (N,K) shape.  With ``family`` the
+    pairs go around EVERY long-K call (K + K2 >= 4096: the four-wave kernel family - plain, gate/up + SwiGLU, masked-pair
+    dgrads, each with its tail launches) and carry the call's FLOPs; that mode costs ~2 events per GEMM and is only used
+    outside a timed region."""
 
-    def __init__(self, N, K):
+    def __init__(self, N, K, family=False):
         self.N, self.K, self.M = N, K, 0
         self.pairs = []
+        self.family = family
+        self.calls = []                      # family mode: (kind, flops, e0, e1)
 
     def result(self):
         torch.cuda.synchronize()
@@ -41,19 +46,58 @@ class _GemmProbe:
         ms = [a.elapsed_time(b) for a, b in self.pairs]
         return sum(ms) / len(ms), len(ms), (self.M, self.N, self.K)
 
+    def family_result(self):
+        """{kind: (calls, total ms, total TFLOP)} over everything recorded."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, e0, e1 in self.calls:
+            c = out.setdefault(kind, [0, 0.0, 0.0])
+            c[0] += 1
+            c[1] += e0.elapsed_time(e1)
+            c[2] += flops / 1e12
+        return out
+
 
 _probe = None
 
 
-def enable_gemm_probe(N, K):
+def enable_gemm_probe(N, K, family=False):
     global _probe
-    _probe = _GemmProbe(N, K)
+    _probe = _GemmProbe(N, K, family)
     return _probe
 
 
 def disable_gemm_probe():
     global _probe
     _probe = None
+
+
+class _Timed:
+    """Context for one GEMM call: the (N, K) probe and / or the family probe."""
+
+    def __init__(self, kind, M, N, K, K2=0):
+        pr = _probe
+        self.e = None
+        if pr is None:
+            return
+        shape = N == pr.N and K == pr.K and kind != "masked"
+        fam = pr.family and K + K2 >= 4096
+        if not (shape or fam):
+            return
+        self.e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if shape and not pr.family:
+            pr.M = M
+            pr.pairs.append(self.e)
+        if fam:
+            pr.calls.append((kind, 2.0 * M * N * (K + K2)) + self.e)
+
+    def __enter__(self):
+        if self.e:
+            self.e[0].record()
+
+    def __exit__(self, *a):
+        if self.e:
+            self.e[1].record()
 
 
 _gemm_ws = {}
@@ -84,20 +128,13 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, a2=None, w2=None, out=Non
     if a2 is not None:
         K2 = a2.shape[1]
         assert w2.shape == (N, K2) and a2.shape[0] == M
-    timed = _probe is not None and N == _probe.N and K == _probe.K
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        _probe.M = M
-        _probe.pairs.append((e0, e1))
-        e0.record()
     ws = _gemm_workspace(a.device) if K + K2 >= 4096 and M * N > 256 * 192 * 256 else None    # more than one wave of tiles
-    check(lib.vlb_gemm_bf16_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                               M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
-                               _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
-                               w2.stride(0) if w2 is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
-                               _stream()), "vlb_gemm_bf16")
-    if timed:
-        e1.record()
+    with _Timed("plain", M, N, K, K2):
+        check(lib.vlb_gemm_bf16_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                   M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, act,
+                                   _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2),
+                                   w2.stride(0) if w2 is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
+                                   _stream()), "vlb_gemm_bf16")
     return out
 
 
@@ -115,19 +152,12 @@ def gemm_swiglu_save(a, w_il, a2=None, w2_il=None):
     if a2 is not None:
         K2 = a2.shape[1]
         assert w2_il.shape == (N, K2) and a2.shape[0] == M
-    timed = _probe is not None and N == _probe.N and K == _probe.K
-    if timed:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        _probe.M = M
-        _probe.pairs.append((e0, e1))
-        e0.record()
     ws = _gemm_workspace(a.device) if K + K2 >= 4096 and M * N > 256 * 192 * 256 else None
-    check(lib.vlb_gemm_swiglu_save(a.data_ptr(), a.stride(0), w_il.data_ptr(), w_il.stride(0), h.data_ptr(), h.stride(0),
-                                   gu.data_ptr(), gu.stride(0), M, N, K, _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2_il),
-                                   w2_il.stride(0) if w2_il is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
-                                   _stream()), "vlb_gemm_swiglu_save")
-    if timed:
-        e1.record()
+    with _Timed("gate_up+swiglu", M, N, K, K2):
+        check(lib.vlb_gemm_swiglu_save(a.data_ptr(), a.stride(0), w_il.data_ptr(), w_il.stride(0), h.data_ptr(), h.stride(0),
+                                       gu.data_ptr(), gu.stride(0), M, N, K, _p(a2), a2.stride(0) if a2 is not None else 0, _p(w2_il),
+                                       w2_il.stride(0) if w2_il is not None else 0, K2, _p(ws), ws.numel() if ws is not None else 0,
+                                       _stream()), "vlb_gemm_swiglu_save")
     return h, gu
 
 
@@ -145,10 +175,11 @@ def gemm_masked_pair(a, w, a2, w2, p, seed, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=BF16, device=a.device)
     ws = _gemm_workspace(a.device) if K + 64 >= 4096 and M * N > 256 * 192 * 256 else None
-    check(lib.vlb_gemm_bf16_masked_pair_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                                           M, N, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), float(p),
-                                           int(seed) & 0xFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream()),
-          "vlb_gemm_bf16_masked_pair")
+    with _Timed("masked", M, N, K, 64):
+        check(lib.vlb_gemm_bf16_masked_pair_ws(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                                               M, N, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(), w2.stride(0), float(p),
+                                               int(seed) & 0xFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream()),
+              "vlb_gemm_bf16_masked_pair")
     return out
 
 
@@ -162,10 +193,11 @@ def gemm_masked_pair_swiglu_bwd(dy, w_t, gu, a2, w2, p, seed, out=None):
     if out is None:
         out = torch.empty(M, 2 * ff, dtype=BF16, device=dy.device)
     ws = _gemm_workspace(dy.device) if K + 64 >= 4096 and M * ff > 256 * 192 * 256 else None
-    check(lib.vlb_gemm_masked_pair_swiglu_bwd(dy.data_ptr(), dy.stride(0), w_t.data_ptr(), w_t.stride(0), gu.data_ptr(), gu.stride(0),
-                                              out.data_ptr(), out.stride(0), M, ff, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(),
-                                              w2.stride(0), float(p), int(seed) & 0xFFFFFFFF, _p(ws),
-                                              ws.numel() if ws is not None else 0, _stream()), "vlb_gemm_masked_pair_swiglu_bwd")
+    with _Timed("masked", M, ff, K, 64):
+        check(lib.vlb_gemm_masked_pair_swiglu_bwd(dy.data_ptr(), dy.stride(0), w_t.data_ptr(), w_t.stride(0), gu.data_ptr(), gu.stride(0),
+                                                  out.data_ptr(), out.stride(0), M, ff, K, a2.data_ptr(), a2.stride(0), w2.data_ptr(),
+                                                  w2.stride(0), float(p), int(seed) & 0xFFFFFFFF, _p(ws),
+                                                  ws.numel() if ws is not None else 0, _stream()), "vlb_gemm_masked_pair_swiglu_bwd")
     return out
 
 

@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_four_wave_gemm_k_loops_stay_in_registers(tmp_path):
     """Every K loop of gemm_w4_kernel holds exactly its 2 x MT x NT MFMAs, MT + NT LDS-DMA pieces and 2 (MT + NT) fragment
     reads, and touches neither scratch memory nor v_accvgpr_* copies (tools/audit_gemm_isa.py explains why that can break
-    without any change to the loop's source)."""
+    without any change to the loop's source).  (`python tools/audit_gemm_isa.py --tools` also audits the tools build's
+    gemm_wd_kernel - hand-assigned W registers v[192:255]: counts and waits of its loop, no compiler-issued access to that range
+    in the K region, W loads / MFMA W operands inside it, the double buffer's read / fill alternation.)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_gemm_isa as A
     import subprocess
@@ -23,5 +25,5 @@ def test_four_wave_gemm_k_loops_stay_in_registers(tmp_path):
                    ["-S", "--cuda-device-only", os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     report, bad = A.audit(out)
-    assert len(report) >= 8, report
+    assert len(report) >= 8 and not any("gemm_wd_kernel" in r for r in report), report     # the W-direct experiment is not in the product
     assert not bad, "\n".join(bad)

@@ -30,12 +30,89 @@ def k_loops(body):
                 yield seg
 
 
+def _vregs(text):
+    """VGPR indices an instruction line names (v7, v[8:11])."""
+    out = []
+    for lo, hi in re.findall(r"\bv\[?(\d+)(?::(\d+))?\]?", text.split(";")[0]):
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def audit_wd(body):
+    """gemm_wd_kernel: the W double buffer is hand-assigned to v[192:255] (loads and MFMAs name the registers literally).
+    Checked on the generated ISA: (1) the hot loop (two K-tiles per iteration) holds exactly 256 MFMA, 16 LDS-DMA pieces, 16
+    W loads, 64 ds_read_b128, 2 barriers, 4 x lgkmcnt(0) + 4 x counted vmcnt(8) and nothing else that waits, no scratch access,
+    no v_accvgpr copy; (2) between the first W load and the last MFMA of the kernel NO compiler-issued instruction (outside
+    the asm statements) names a register >= v192; (3) every W load writes, and every MFMA reads its W operand from, that range,
+    and inside the loop the MFMAs of a K-tile read only the buffer that the PREVIOUS tile's loads filled."""
+    report, bad = [], []
+    hdr = [k for k, l in enumerate(body) if "Inner Loop Header" in l]
+    if not hdr:
+        return ["gemm_wd_kernel: no K loop found"], ["gemm_wd_kernel: no K loop found"]
+    h = hdr[0]
+    label = body[h].split(":")[0]
+    back = [k for k, l in enumerate(body) if k > h and re.search(r"s_c?branch\w* " + re.escape(label) + r"\b", l)]
+    loop = body[h:back[0] + 1]
+    cnt = lambda seg, pat: sum(bool(re.search(pat, x.split(";")[0])) for x in seg)
+    waits = [x.strip() for x in loop if "s_waitcnt" in x]
+    got = dict(mfma=cnt(loop, r"v_mfma"), dma=cnt(loop, r"global_load_lds"), wload=cnt(loop, r"global_load_dwordx4 v\["),
+               rd=cnt(loop, r"ds_read_b128"), scratch=cnt(loop, r"scratch_"), acc=cnt(loop, r"v_accvgpr"), barrier=cnt(loop, r"s_barrier"))
+    want = dict(mfma=256, dma=16, wload=16, rd=64, scratch=0, acc=0, barrier=2)
+    line = "gemm_wd_kernel: K loop (2 tiles) " + ", ".join(f"{v} {k}" for k, v in got.items()) + f", waits {sorted(set(waits))}"
+    report.append(line)
+    if got != want or sorted(waits) != sorted(["s_waitcnt lgkmcnt(0)"] * 4 + ["s_waitcnt vmcnt(8)"] * 4):
+        bad.append(line)
+    first = min(k for k, l in enumerate(body) if re.search(r"global_load_dwordx4 v\[", l))
+    last = max(k for k, l in enumerate(body) if "v_mfma" in l)
+    inasm, viol = False, []
+    for x in body[first - 1:last + 1]:
+        if "ASMSTART" in x:
+            inasm = True
+        elif "ASMEND" in x:
+            inasm = False
+        elif not inasm and not x.strip().startswith(";") and any(r >= 192 for r in _vregs(x)):
+            viol.append(x.strip())
+    for x in body[first:last + 1]:
+        m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", x)
+        if m and not (192 <= int(m.group(1)) and int(m.group(2)) <= 255):
+            viol.append("W load outside v[192:255]: " + x.strip())
+        m = re.search(r"v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[(\d+):(\d+)\]", x)
+        if m and not (192 <= int(m.group(1)) and int(m.group(2)) <= 255):
+            viol.append("MFMA W operand outside v[192:255]: " + x.strip())
+    # buffer discipline inside the loop: tile of parity P reads v[192+32P, +32) and loads v[192+32(1-P), +32)
+    seq = []
+    for x in loop:
+        m = re.search(r"global_load_dwordx4 v\[(\d+):", x)
+        if m:
+            seq.append(("L", (int(m.group(1)) - 192) // 32))
+        m = re.search(r"v_mfma_f32_16x16x32_bf16 a\[\d+:\d+\], v\[(\d+):", x)
+        if m:
+            seq.append(("M", (int(m.group(1)) - 192) // 32))
+    mf = [b for k, b in seq if k == "M"]
+    half = len(mf) // 2
+    ok = mf[:half] == [0] * half and mf[half:] == [1] * half
+    pos = [i for i, (k, _) in enumerate(seq) if k == "M"]
+    for i, (k, b) in enumerate(seq):
+        if k == "L":
+            tile_par = 0 if i < pos[half - 1] else 1          # a tile's first W load is issued in front of its first MFMA
+            ok = ok and b == 1 - tile_par
+    report.append(f"gemm_wd_kernel: {len(viol)} compiler accesses to v[192:255] in the K region; W buffer discipline {'ok' if ok else 'BROKEN'}")
+    if viol or not ok:
+        bad.append(report[-1] + " " + "; ".join(viol[:4]))
+    return report, bad
+
+
 def audit(asm_path):
     lines = open(asm_path).read().split("\n")
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
     ends = [i for i, l in enumerate(lines) if l.startswith(".Lfunc_end")]
     report, bad = [], []
     for i, name in starts:
+        if "gemm_wd_kernel" in name:
+            r, b = audit_wd(lines[i:min(x for x in ends if x > i)])
+            report += r
+            bad += b
+            continue
         if "gemm_w4_kernel" not in name:
             continue
         body = lines[i:min(x for x in ends if x > i)]
@@ -61,7 +138,8 @@ def audit(asm_path):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "gemm.s")
-        subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only",
+        # -DVLB_TOOLS: the tools build holds everything the product build holds plus the experiment kernels (gemm_wd_kernel)
+        subprocess.run([HIPCC] + FLAGS + (["-DVLB_TOOLS"] if "--tools" in sys.argv else []) + ["-S", "--cuda-device-only",
                         os.path.join(ROOT, "phantom_vlb_amd", "csrc", "gemm.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         report, bad = audit(out)
     print("\n".join(report))
