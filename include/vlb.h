@@ -404,6 +404,15 @@ int vlb_gemm_mxfp8(const void* Aq, int lda, const void* sA, int ldsa, const void
 int vlb_comm_unique_id(void* id128_host);                                     /* host buffer of 128 bytes (rank 0) */
 int vlb_comm_init(int rank, int world, const void* id128_host, void** comm_out);
 int vlb_comm_destroy(void* comm);
+/* Loopback transport (testing the exchange schedules without a second GPU): `world` communicators in ONE process whose
+ * ncclSend / ncclRecv calls are replaced by device copies paired through an in-process mailbox with the same stream
+ * ordering (receiver waits for the sender's stream, sender waits for the copy).  vlb_allgather_direct,
+ * vlb_reducescatter_direct(_bf16) and vlb_allreduce_scalar then run unchanged with world 2..8 on one GPU - every rank
+ * MUST be driven by its own host thread (a group blocks until its peers arrive; 60 s without them is an error, not a
+ * hang).  `stage`: caller-owned device memory of vlb_comm_loopback_stage_bytes(world) bytes for the all-reduce, alive
+ * until the last communicator is destroyed.  comms_out[world].  tests/test_gpu_comm.py drives it. */
+int64_t vlb_comm_loopback_stage_bytes(int world);
+int vlb_comm_init_loopback(int world, void* stage, int64_t stage_bytes, void** comms_out);
 int vlb_comm_rank(void* comm);
 int vlb_comm_world(void* comm);
 /* full[r*shard_bytes ...] = rank r's shard, for every r.  In place when shard == full + rank*shard_bytes. */

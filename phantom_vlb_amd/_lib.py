@@ -97,6 +97,8 @@ SIGNATURES = {
     "vlb_comm_unique_id": [P],
     "vlb_comm_init": [I, I, P, ctypes.POINTER(c_void_p)],
     "vlb_comm_destroy": [P],
+    "vlb_comm_loopback_stage_bytes": [I],
+    "vlb_comm_init_loopback": [I, P, L, ctypes.POINTER(c_void_p)],
     "vlb_comm_rank": [P],
     "vlb_comm_world": [P],
     "vlb_allgather_direct": [P, P, P, L, P],
@@ -114,7 +116,7 @@ SIGNATURES = {
     "vlb_cast_bf16_to_f32": [P, P, L, P],
 }
 _RESTYPES = {"vlb_last_error": c_char_p, "vlb_hrf_pool_ws_floats": c_int64, "vlb_ridge_ws_floats": c_int64, "vlb_head_ws_floats": c_int64, "vlb_wgrad_u_ws_floats": c_int64,
-             "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64,
+             "vlb_gemm_workspace_bytes": c_int64, "vlb_reducescatter_stage_floats": c_int64, "vlb_comm_loopback_stage_bytes": c_int64,
              "vlb_norm_bwd_ws_floats": c_int64, "vlb_rmsnorm_bwd_full_ws_floats": c_int64, "vlb_colsum_ws_floats": c_int64, "vlb_dwconv3x3_bwd_w_ws_floats": c_int64}
 
 

@@ -272,6 +272,238 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
+#ifdef VLB_TOOLS
+// -------------------------------------------------------------------------------------------------
+// Forward, 64 query rows per wave (round 4 EXPERIMENT, tools build only: measured 39-45 % SLOWER, see below).
+// The kernel above is LDS-bound: per 64-key tile a wave reads 16 K fragments
+// (ds_read_b128) and 32 transposed V^T fragments (ds_read_b64_tr_b16) = 32 KB for 32 MFMAs, and with eight waves on a CU
+// that is ~250 B/clk against the 256 B/clk the LDS delivers.  Here a wave owns TWO 32-row query blocks and every K and
+// V^T fragment it reads feeds both (half the LDS bytes per MFMA); a workgroup = 4 waves = 256 query rows, ONE per CU, one
+// wave per SIMD with the 512-register budget (2 x 64 accumulator registers of O^T, 2 x 32 of S^T, 2 x 32 registers of Q
+// fragments).  Same arithmetic per row as the kernel above (same tile order, same online-softmax updates): bit-identical.
+// Measured (tools/bench_attention.py, interleaved): decoder B=3 231.8 vs 140.3 us, B=5 356.4 vs 218.3, ViT D=64 165.5 vs 90.9 -
+// with ONE compiler-scheduled wave per SIMD nothing covers a fragment read's latency or the softmax's VALU work (the two
+// waves per SIMD of the kernel above cover each other's); halving the LDS bytes does not pay for that.  The structure needs
+// a hand-placed instruction stream (cdna guide, "4-wave, one-wave-per-SIMD" forward), which was not attempted.
+// -------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(AttnArgs p) {
+  constexpr int CPR = D / 8, ROWB = D * 2, TILE = KV * ROWB, LD = (KV * CPR) / 256, KS = D / 16, DT = D / 32;
+  constexpr int NQ = 2, QWW = 32 * NQ, QBB = QWW * NW;          // 64 rows per wave, 256 per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.S + QBB - 1) / QBB;
+  const int per_qb = p.Hq * p.B, slot = blockIdx.x / per_qb;
+  const int qb = CAUSAL ? (nqb - 1 - slot) : slot;
+  const int hq = xcd_head((blockIdx.x % per_qb) % p.Hq, p.Hq), b = (blockIdx.x % per_qb) / p.Hq;
+  const int hkv = hq / (p.Hq / p.Hkv);
+  const int Sb = p.cu ? p.cu[b + 1] - p.cu[b] : p.S;
+  const int64_t row0 = p.cu ? p.cu[b] : (int64_t)b * p.S;
+  if (qb * QBB >= Sb) return;
+  const int q0 = qb * QBB + wave * QWW;  // first query row of this wave (a multiple of 64: both blocks see the same tiles)
+  const int ql = lane & 31, h = lane >> 5;
+
+  bf16x8 qf[NQ][KS];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) {
+    const int qr = min(q0 + 32 * u + ql, Sb - 1);
+    const bf16* qp = p.q + (row0 + qr) * p.ldq + hq * D + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+  f32x16 ot[NQ][DT];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[u][i][r] = 0.f;
+  float m_run[NQ], l_run[NQ];
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) { m_run[u] = NEG; l_run[u] = 0.f; }
+  const float c2 = p.scale * 1.44269504088896341f;
+
+  const int q_hi = min(qb * QBB + QBB, Sb) - 1;
+  const int ntiles = CAUSAL ? (q_hi / KV + 1) : (Sb + KV - 1) / KV;
+  const bf16* kbase = p.k + row0 * p.ldk + hkv * D;
+  const bf16* vbase = p.v + row0 * p.ldv + hkv * D;
+  constexpr int RPI = 1024 / ROWB;
+  const int sr = lane / CPR, sp = lane % CPR;
+  auto stage = [&](int buf, int t) {
+    char* kb = smem + buf * 2 * TILE; char* vb = kb + TILE;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int r = (4 * i + wave) * RPI + sr;
+      const int key = min(t * KV + r, Sb - 1);
+      glds16(kbase + (int64_t)key * p.ldk + slot_k<D>(r, sp) * 8, kb + (4 * i + wave) * 1024);
+      glds16(vbase + (int64_t)key * p.ldv + slot_v<D>(r, sp) * 8, vb + (4 * i + wave) * 1024);
+    }
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int g1 = (lane >> 4) & 1, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int k_rd[KS], v_rd[DT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = ql * ROWB + slot_k<D>(ql, 2 * ks + h) * 16;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const int r0 = 4 * h + tq;
+    v_rd[dt] = r0 * ROWB + slot_v<D>(r0, 4 * dt + 2 * g1 + (tp >> 1)) * 16 + (tp & 1) * 8;
+  }
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+    const char* kb = smem + cur * 2 * TILE; const char* vb = kb + TILE;
+    const int key0 = t * KV;
+    const bool active = !CAUSAL || (key0 <= q0 + QWW - 1);
+    if (active) {
+      // ---- S^T = K . Q^T for both query blocks: one K fragment, two MFMAs
+      f32x16 st[NQ][2];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[u][s][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + k_rd[ks] + 32 * s * ROWB);
+#pragma unroll
+          for (int u = 0; u < NQ; ++u) st[u][s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], st[u][s], 0, 0, 0);
+        }
+      }
+      unsigned long long kvalid;
+      {
+        const int key = key0 + lane;
+        bool ok = key < Sb;
+        if (ok && p.mask) ok = p.mask[row0 + key] != 0;
+        kvalid = __ballot(ok);
+      }
+      float alpha[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int qu0 = q0 + 32 * u;
+        const bool diag = CAUSAL && (key0 + KV - 1 > qu0);
+        const bool partial = diag || (kvalid != ~0ull);
+        if (partial) {
+          const int qrow = qu0 + ql;
+          const unsigned lo = (unsigned)(kvalid >> (4 * h)), hi = (unsigned)(kvalid >> (32 + 4 * h));
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const unsigned word = s ? hi : lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int kb2 = (r & 3) + 8 * (r >> 2);
+              bool ok = (word >> kb2) & 1u;
+              if (CAUSAL) ok = ok && (key0 + 32 * s + 4 * h + kb2 <= qrow);
+              st[u][s][r] = ok ? st[u][s][r] : NEG;
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+        float mloc = fmaxf(st[u][0][0], st[u][1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, st[u][0][r]), st[u][1][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run[u], mloc);
+        alpha[u] = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c2);
+        const float mc = m_new * c2;
+        float lsum = 0.f;
+        const float live = (m_new > 0.5f * NEG) ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[u][s][r] * c2 - mc);
+            st[u][s][r] = e;
+            lsum += e;
+          }
+        if (partial && live == 0.f) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[u][s][r] = 0.f;
+          lsum = 0.f;
+        }
+        l_run[u] = l_run[u] * alpha[u] + lsum;
+        m_run[u] = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[u][i][r] *= alpha[u];
+      }
+      // ---- O^T += V^T . P^T: one transposed V^T fragment, two MFMAs
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf[NQ];
+#pragma unroll
+          for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[u][j] = (bf16)st[u][s][8 * s2 + j];
+          const int roff = (32 * s + 16 * s2) * ROWB;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(vb + v_rd[dt] + roff + 8 * ROWB));
+            const bf16x8 vt = join8(lo, hi);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) ot[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf[u], ot[u][dt], 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) {
+    const float l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int qrow = q0 + 32 * u + ql;
+    if (qrow < Sb) {
+      bf16* op = p.o + (row0 + qrow) * p.ldo + hq * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[u][dt][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(op + 32 * dt + 8 * g + 4 * h) = o;
+        }
+      if (p.lse && h == 0)
+        p.lse[((int64_t)b * p.Hq + hq) * p.S + qrow] = l_tot > 0.f ? m_run[u] * p.scale + logf(l_tot) : -INFINITY;
+    }
+  }
+}
+
+int g_attn_fwd64 = 0;          // tools: bit 0 = 64-row waves in the forward for D = 128 (decoder), bit 1 = for D = 64 (ViT)
+
+template <int D, bool CAUSAL>
+int launch_fwd64(const AttnArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * 2 * KV * D * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd64_kernel<D, CAUSAL>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr != hipSuccess) { vlb_set_error("attention: LDS reservation failed: %s", hipGetErrorString(attr)); return VLB_ERR_LAUNCH; }
+  dim3 grid(((a.S + 255) / 256) * a.Hq * a.B);
+  hipLaunchKernelGGL((attn_fwd64_kernel<D, CAUSAL>), grid, dim3(256), LDS, s, a);
+  VLB_LAUNCH_CHECK();
+  return VLB_OK;
+}
+
+#endif  // VLB_TOOLS (64-rows-per-wave forward experiment)
+
 template <int D, bool CAUSAL>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * 2 * KV * D * 2;
@@ -296,9 +528,18 @@ extern "C" int vlb_attention_fwd(const void* q, int ldq, const void* k, int ldk,
   VLB_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0) && ((uintptr_t)out % 8 == 0), "attention_fwd: misaligned pointer");
   AttnArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, lse, key_mask, cu_rows, ldq, ldk, ldv, ldo, B, S, Hq, Hkv, scale};
   hipStream_t s = as_stream(stream);
+#ifdef VLB_TOOLS
+  if ((int64_t)((S + 255) / 256) * Hq * B >= 256) {          // A/B of the 64-rows-per-wave experiment
+    if (D == 128 && (g_attn_fwd64 & 1)) return causal ? launch_fwd64<128, true>(a, s) : launch_fwd64<128, false>(a, s);
+    if (D == 64 && (g_attn_fwd64 & 2)) return causal ? launch_fwd64<64, true>(a, s) : launch_fwd64<64, false>(a, s);
+  }
+#endif
   if (D == 128) return causal ? launch_fwd<128, true>(a, s) : launch_fwd<128, false>(a, s);
   return causal ? launch_fwd<64, true>(a, s) : launch_fwd<64, false>(a, s);
 }
+#ifdef VLB_TOOLS
+extern "C" void vlb_attn_set_fwd64(int on) { g_attn_fwd64 = on; }
+#endif
 
 // =================================================================================================
 // Backward (D = 128 only: the decoder; the frozen ViT never needs one).

@@ -16,6 +16,25 @@ from ._lib import check, lib
 
 
 class DirectComm:
+    @classmethod
+    def loopback(cls, world: int, device=None):
+        """`world` DirectComm objects in THIS process on libvlb's loopback transport (vlb_comm_init_loopback): the same
+        schedules and the same Python wrapper code as over RCCL, with ranks 0..world-1 driven by one host thread each
+        (tests/test_gpu_comm.py) - the way to exercise offsets and pairing at world 2..8 on a one-GPU box."""
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        stage = torch.zeros(lib.vlb_comm_loopback_stage_bytes(world) // 4, dtype=torch.float32, device=device)
+        handles = (ctypes.c_void_p * world)()
+        check(lib.vlb_comm_init_loopback(world, stage.data_ptr(), stage.numel() * 4, handles), "vlb_comm_init_loopback")
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c.group, c.world, c.rank = None, world, r
+            c._h = ctypes.c_void_p(handles[r])
+            c._stage, c._loop_stage = None, stage             # the staging buffer lives as long as any communicator
+            c.stream = torch.cuda.Stream(device=device)
+            out.append(c)
+        return out
+
     def __init__(self, group=None, stream=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -56,3 +56,74 @@ def test_sharded_step_through_direct_comm_equals_plain_step(dev):
         torch.cuda.synchronize()
         outs.append((m.flat.master.clone(), m.flat.compute.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_direct_schedules_on_the_loopback_transport(dev, world):
+    """The all-pairs exchange code of vlb_allgather_direct / vlb_reducescatter_direct(_bf16) / vlb_allreduce_scalar - peer
+    loops, slice offsets, staging layout, rank-ordered reduction - with world 2..8 on ONE GPU: `world` communicators in this
+    process (vlb_comm_init_loopback: ncclSend / ncclRecv replaced by stream-ordered device copies paired through a mailbox),
+    every rank driven by its own host thread through the same DirectComm wrapper the RCCL path uses.  Every rank's result is
+    compared with a torch reference built from ALL ranks' inputs: reduce-scatter bit-exact against the rank-ordered fp32 sum
+    (bf16 slices: fp32 accumulation, one rounding), all-gather exact (also in place), scalar all-reduce exact.  Two rounds
+    per collective, so FIFO pairing and the all-reduce's double-buffered staging are exercised too.  (RCCL itself has only
+    ever run at world 1 here: no multi-GPU box.)"""
+    import threading
+    from phantom_vlb_amd.parallel_native import DirectComm
+    comms = DirectComm.loopback(world)
+    assert [c.rank for c in comms] == list(range(world)) and all(c.world == world for c in comms)
+    n, nb, m = 4 * 1531, 8 * 517, 1000          # per-rank slice sizes (fp32 reduce-scatter, bf16 reduce-scatter, all-gather shard)
+    gen = torch.Generator(device=dev).manual_seed(100 + world)
+    rounds = 2
+    x = [[torch.randn(world * n, device=dev, generator=gen) for _ in range(world)] for _ in range(rounds)]
+    y = [[torch.randn(world * nb, device=dev, generator=gen).bfloat16() for _ in range(world)] for _ in range(rounds)]
+    sh = [[torch.randn(m, device=dev, generator=gen).bfloat16() for _ in range(world)] for _ in range(rounds)]
+    sc = [[torch.randn(3, device=dev, generator=gen) for _ in range(world)] for _ in range(rounds)]
+    res = [[None] * world for _ in range(rounds)]
+    errors = []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(dev)
+            c = comms[r]
+            for k in range(rounds):
+                out = torch.zeros(n, device=dev)
+                outb = torch.zeros(nb, dtype=torch.bfloat16, device=dev)
+                full = torch.zeros(world * m, dtype=torch.bfloat16, device=dev)
+                inplace = torch.zeros(world * m, dtype=torch.bfloat16, device=dev)
+                inplace[r * m:(r + 1) * m] = sh[k][r]
+                s = sc[k][r].clone()
+                c.reduce_scatter(out, x[k][r]).wait()
+                c.reduce_scatter(outb, y[k][r]).wait()
+                c.all_gather(full, sh[k][r]).wait()
+                c.all_gather(inplace, inplace[r * m:(r + 1) * m]).wait()
+                c.all_reduce_scalar(s)
+                res[k][r] = (out, outb, full, inplace, s)
+            torch.cuda.synchronize()
+        except Exception as e:       # surfaced below: a failing rank must not leave the others waiting silently
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    torch.cuda.synchronize()
+    for k in range(rounds):
+        gathered = torch.cat(sh[k])
+        ssum = sc[k][0].clone()
+        for q in range(1, world):
+            ssum = ssum + sc[k][q]
+        for r in range(world):
+            out, outb, full, inplace, s = res[k][r]
+            ref = x[k][0][r * n:(r + 1) * n].clone()
+            refb = y[k][0][r * nb:(r + 1) * nb].float()
+            for q in range(1, world):                       # rank order, fp32
+                ref = ref + x[k][q][r * n:(r + 1) * n]
+                refb = refb + y[k][q][r * nb:(r + 1) * nb].float()
+            assert torch.equal(out, ref), (world, k, r, "reduce-scatter fp32")
+            assert torch.equal(outb, refb.bfloat16()), (world, k, r, "reduce-scatter bf16")
+            assert torch.equal(full, gathered) and torch.equal(inplace, gathered), (world, k, r, "all-gather")
+            assert torch.equal(s, ssum), (world, k, r, "all-reduce")
+    del comms

@@ -29,6 +29,33 @@ def timeit(fn, n=10):
 
 
 fwd_flops = 4.0 * B * Hq * S * S * D / 2
+if hasattr(lib, "vlb_attn_set_fwd64"):
+    # forward: 32 rows per wave (two workgroups per CU) vs 64 rows per wave (one), interleaved rounds; outputs must be bit-equal
+    lib.vlb_attn_set_fwd64.argtypes = [ctypes.c_int]; lib.vlb_attn_set_fwd64.restype = None
+    cases = [("decoder D=128 causal", qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, Hq, Hkv, D, True, mask, 1),
+             ("decoder D=128 causal B=5", None, None, None, 5, S, Hq, Hkv, D, True, None, 1)]
+    T, SV, HV, DV = 36, 577, 16, 64
+    vq = (torch.randn(T * SV, 3 * HV * DV, device=dev) * 0.5).bfloat16()
+    cases.append(("ViT D=64 full", vq[:, :HV * DV], vq[:, HV * DV:2 * HV * DV], vq[:, 2 * HV * DV:], T, SV, HV, HV, DV, False, None, 2))
+    for name, q_, k_, v_, b_, s_, hq_, hkv_, d_, causal, m_, bit in cases:
+        if q_ is None:
+            x_ = (torch.randn(b_ * s_, hq_ * d_ + 2 * hkv_ * d_, device=dev) * 0.5).bfloat16()
+            q_, k_, v_ = x_[:, :hq_ * d_], x_[:, hq_ * d_:hq_ * d_ + hkv_ * d_], x_[:, hq_ * d_ + hkv_ * d_:]
+        fn = lambda: ops.attention_fwd(q_, k_, v_, b_, s_, hq_, hkv_, d_, causal, d_ ** -0.5, key_mask=m_, need_lse=True)
+        res, times = [], ([], [])
+        for v in (0, bit):
+            lib.vlb_attn_set_fwd64(v)
+            o_, l_ = fn()
+            res.append((o_.clone(), l_.clone()))
+        for rnd in range(6):
+            for idx in ((0, 1) if rnd % 2 == 0 else (1, 0)):
+                lib.vlb_attn_set_fwd64((0, bit)[idx])
+                times[idx].append(timeit(fn) * 1e6)
+        lib.vlb_attn_set_fwd64(0)
+        same = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        fl = 4.0 * b_ * hq_ * s_ * s_ * d_ / (2 if causal else 1)
+        print(f"fwd {name:26s} equal={same}  32-row waves: min {min(times[0]):7.1f} us ({fl / min(times[0]) / 1e6:6.1f} TF) | 64-row waves: min {min(times[1]):7.1f} us "
+              f"({fl / min(times[1]) / 1e6:6.1f} TF)  ({(min(times[0]) / min(times[1]) - 1) * 100:+.1f} %)", flush=True)
 out, lse = ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, Hq, Hkv, D, True, D ** -0.5, key_mask=mask, need_lse=True)
 t = timeit(lambda: ops.attention_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], B, S, Hq, Hkv, D, True, D ** -0.5, key_mask=mask, need_lse=True))
 print(f"fwd  {t*1e6:8.1f} us  {fwd_flops/t/1e12:6.1f} TF/s")

@@ -173,7 +173,9 @@ def sq(d, out):
     print(open(out).read()[:3000])
 
 
-def traffic(dfetch, dwrite, out):
+def traffic(dfetch, dwrite, out, workload="lora"):
+    """workload 'lora' (default bench: vlb_gemm_swiglu_save, M = 5861) or 'frozen' (--workload frozen: the SwiGLU-fused
+    vlb_gemm_bf16 call; run with VLB_ROWS=9447)."""
     res = {}
     for d, c in ((dfetch, "FETCH_SIZE"), (dwrite, "WRITE_SIZE")):
         f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
@@ -195,22 +197,32 @@ def traffic(dfetch, dwrite, out):
     fm, ft = res["FETCH_SIZE"][2], res["FETCH_SIZE"][3]
     wm, wt = res["WRITE_SIZE"][2], res["WRITE_SIZE"][3]
     total = (2 * (fm + ft) + wm + wt) * 1024
-    alg = 2.0 * (M * (E + 64) + 2 * FF * (E + 64)) + 2.0 * M * 2 * FF + 2.0 * M * FF      # A|t, W|B, saved [gate|up] [M,2FF], h = silu(gate)*up [M,FF]
+    frozen = workload == "frozen"
+    if frozen:
+        alg = 2.0 * (M * E + 2 * FF * E) + 2.0 * M * FF                                      # A, W, h = silu(gate)*up [M,FF]
+    else:
+        alg = 2.0 * (M * (E + 64) + 2 * FF * (E + 64)) + 2.0 * M * 2 * FF + 2.0 * M * FF      # A|t, W|B, saved [gate|up] [M,2FF], h = silu(gate)*up [M,FF]
     with open(out, "w") as o:
-        o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (default LoRA workload, packed rows)\n")
-        o.write("# one gate/up GEMM CALL (vlb_gemm_swiglu_save: GEMM + SwiGLU + saved pre-activations) = main gemm_w4_kernel launch (10 full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
+        if frozen:
+            o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --workload frozen --steps 1 --warmup 1 --no-cpu-baseline` (packed rows)\n")
+            o.write("# one gate/up GEMM CALL (vlb_gemm_bf16_ws, SwiGLU fused in the epilogue) = main gemm_w4_kernel launch (full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
+        else:
+            o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (default LoRA workload, packed rows)\n")
+            o.write("# one gate/up GEMM CALL (vlb_gemm_swiglu_save: GEMM + SwiGLU + saved pre-activations) = main gemm_w4_kernel launch (10 full waves of tiles) + its split-K tail launch + the reduce launch; KB per call, means over the calls of the run\n")
         o.write("# gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -> corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024\n")
         o.write("counter,main_grid_threads,calls,main_mean_kb,tail_mean_kb\n")
         for c, (g, n, a, b) in res.items():
             o.write(f"{c},{g},{n},{a:.1f},{b:.1f}\n")
-        o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} (A|t + W|B + saved [gate|up] [M,N] + h [M,N/2], bf16); ratio {total / alg:.2f}\n")
+        what_alg = "A + W + h [M,N/2], bf16" if frozen else "A|t + W|B + saved [gate|up] [M,N] + h [M,N/2], bf16"
+        o.write(f"# traffic per call = {total:.4e} bytes (main launch alone {(2 * fm + wm) * 1024:.4e}); algorithmic {alg:.4e} ({what_alg}); ratio {total / alg:.2f}\n")
     print(open(out).read())
     # the tracked shape -> bytes table bench.py reads its roofline.traffic from
     import json
     jp = "profiles/gateup_traffic.json"
     tab = json.load(open(jp)) if os.path.exists(jp) else {}
     tab[f"{M},{2 * FF},{E}"] = {"bytes": float(f"{total:.4e}"), "source": out,
-                               "what": "configs[2] default bench (LoRA, packed rows): vlb_gemm_swiglu_save call = main launch + split-K tail + reduce"}
+                               "what": ("--workload frozen (packed rows): SwiGLU-fused vlb_gemm_bf16_ws call = main launch + split-K tail + reduce" if frozen else
+                                        "configs[2] default bench (LoRA, packed rows): vlb_gemm_swiglu_save call = main launch + split-K tail + reduce")}
     json.dump(tab, open(jp, "w"), indent=1)
 
 
@@ -255,5 +267,5 @@ def traffic_fp8(dfetch, dwrite, out):
 
 if __name__ == "__main__":
     {"stats": lambda: stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else ""), "sq": lambda: sq(sys.argv[2], sys.argv[3]),
-     "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4]),
+     "traffic": lambda: traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "lora"),
      "traffic_fp8": lambda: traffic_fp8(sys.argv[2], sys.argv[3], sys.argv[4])}[sys.argv[1]]()
