@@ -5,7 +5,9 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${ROUND:-r04}
+PART=${PART:-all}      # a: LoRA + frozen workloads, b: full fine-tune (bf16, fp8) + HBM-bound kernel bench, all: both (needs ~20 min)
 rm -rf gpurun_out/pf && mkdir -p gpurun_out/pf
+if [ "$PART" != "b" ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/lora -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/pf/lora.log 2>&1
 python3 tools/profile_tables.py stats gpurun_out/pf/lora 8 ${R}_bench_lora7b "default command: the next step's vision side runs on a side stream under the backward pass, so kernel durations overlap (their sum exceeds the step time) and overlapped kernels read slower than alone" > gpurun_out/pf/lora_tables.log 2>&1
 # the same step with everything on one stream: clean per-kernel durations for the kernel split
@@ -22,6 +24,8 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p
 VLB_ROWS=9447 VLB_CLIPS=5 python3 tools/profile_tables.py traffic gpurun_out/pf/fetchf gpurun_out/pf/writef profiles/${R}_gemm_gateup_hbm_traffic_frozen.csv frozen > gpurun_out/pf/trafficf_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/frozen -- python3 bench.py --workload frozen --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/pf/frozen.log 2>&1
 VLB_ROWS=9447 VLB_CLIPS=5 python3 tools/profile_tables.py stats gpurun_out/pf/frozen 8 ${R}_bench_frozen7b > gpurun_out/pf/frozen_tables.log 2>&1
+fi
+if [ "$PART" != "a" ]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/full8 -- python3 bench.py --workload full --fp8 --steps 4 --warmup 2 > gpurun_out/pf/full8.log 2>&1
 python3 tools/profile_tables.py stats gpurun_out/pf/full8 4 ${R}_bench_full7b_fp8 > gpurun_out/pf/full8_tables.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/full -- python3 bench.py --workload full --steps 4 --warmup 2 > gpurun_out/pf/full.log 2>&1
@@ -30,6 +34,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write8 -- python3 bench.py --workload full --fp8 --steps 1 --warmup 1 > gpurun_out/pf/write8.log 2>&1
 python3 tools/profile_tables.py traffic_fp8 gpurun_out/pf/fetch8 gpurun_out/pf/write8 profiles/${R}_gemm_gateup_hbm_traffic_fp8.csv > gpurun_out/pf/traffic8_tables.log 2>&1
 python3 tools/bench_hbm_kernels.py > profiles/${R}_hbm_bound_kernels.txt 2> gpurun_out/pf/hbm.err
+fi
 mkdir -p gpurun_out/pf/out && cp profiles/${R}_* profiles/gateup_traffic.json gpurun_out/pf/out/
 for f in gpurun_out/pf/*_tables.log; do echo "== $f"; tail -n 4 $f; done
 grep -h '"metric"' gpurun_out/pf/*.log || true
