@@ -312,7 +312,11 @@ def main():
                        "parallelism": f"dp{world}: clips sharded over ranks; trainables' gradients reduce-scattered, fp32 master + Adam moments "
                                       f"sharded 1/{world}, bf16 copies all-gathered; frozen weights "
                                       + ("sharded 1/N per layer, all-gathered one layer ahead (fsdp.yaml FULL_SHARD equivalent)"
-                                         if a.shard_frozen else "replicated (--shard-frozen for the fsdp.yaml-equivalent layout)"),
+                                         if a.shard_frozen else "replicated (--shard-frozen for the fsdp.yaml-equivalent layout)")
+                                      + ("" if not full else "; trained decoder weights " + (
+                                          "FULL_SHARD (fsdp.yaml:11): 1/N of every layer per rank, a layer all-gathered for its forward and again for its "
+                                          "backward, one layer ahead" if getattr(getattr(m, "sharded_backbone", None), "full_shard", False)
+                                          else "replicated (SHARD_GRAD_OP / single rank)")),
                        "comm": comm_name, "sharded_frozen_variant": None,
                        "vision_prefetch": (("CLIP tower" if full else "CLIP tower + connector") + " of step i+1 run on a side stream under step i's backward pass (as Trainer.fit's "
                                            "DevicePrefetcher does); each step computes them once, nothing is reused") if pipelined else "off",

@@ -98,11 +98,15 @@ class FlatBackbone:
         self.numel, self.offsets = off, offs
         dev = w.dev
         self.compute = torch.zeros(off, dtype=BF16, device=dev)
-        for name, t, setter, _ in slots:
+        self._setters = {}                              # name -> (setter, segment): release_layers() re-points the views
+        for name, t, setter, seg in slots:
             o, k, shp = offs[name]
             v = self.compute[o:o + k].view(shp)
             v.copy_(t)
             setter(v)                                   # the kernels now read (and AdamW rewrites) the flat buffer
+            self._setters[name] = (setter, seg)
+        self.layers_released = False
+        self.layer_grad_provider = None                 # FULL_SHARD: callable(layer) -> that layer's flat gradient buffer
         del slots
         torch.cuda.empty_cache()
         self.master = torch.empty(off, dtype=torch.float32, device=dev)
@@ -113,12 +117,42 @@ class FlatBackbone:
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
 
+    LAYER_KEYS = ("wqkv", "wo", "wgu", "wdown", "in_norm", "post_norm")
+
     def view(self, buf, name):
         o, k, shp = self.offsets[name]
+        if o + k > buf.numel():
+            raise RuntimeError(f"{name}: this store holds the tail segment only (FULL_SHARD) - layer tensors are reached through "
+                               f"parallel.ShardedFlatState.layer_weights / layer_grads / gather_full")
         return buf[o:o + k].view(shp)
 
     def g_(self, name):
+        if self.layer_grad_provider is not None and name.startswith("layers."):
+            li = int(name.split(".")[1])
+            o, k, shp = self.offsets[name]
+            o -= self.layer_ranges[li][0]
+            return self.layer_grad_provider(li)[o:o + k].view(shp)
         return self.view(self.grad, name)
+
+    def layer_views(self, buf, li: int) -> dict:
+        """The six tensors of decoder layer li as views of a flat layer buffer (a gathered weight or gradient buffer)."""
+        base, out = self.layer_ranges[li][0], {}
+        for key in self.LAYER_KEYS:
+            o, k, shp = self.offsets[f"layers.{li}.{key}"]
+            out[key] = buf[o - base:o - base + k].view(shp)
+        return out
+
+    def release_layers(self):
+        """FULL_SHARD (parallel.ShardedFlatState._enter_full_shard): keep the TAIL segment only.  ``compute`` and ``grad``
+        shrink to it (the tail's kernel views are re-pointed), the full-size fp32 ``master`` goes, every layer view becomes
+        None so that a stale use fails loudly."""
+        T = self.head_range[1]
+        tail = self.compute[:T].clone()
+        for name, (setter, seg) in self._setters.items():
+            o, k, shp = self.offsets[name]
+            setter(tail[o:o + k].view(shp) if seg < 0 else None)
+        self.compute, self.grad, self.master = tail, torch.zeros(T, dtype=BF16, device=tail.device), None
+        self.layers_released = True
 
 
 class FullFineTune:
@@ -135,10 +169,65 @@ class FullFineTune:
         self.wq = {}                          # (layer, key) -> (uint8 e4m3 weights, uint8 scales)
         self.flat = FlatBackbone(g, self.w)
         self.grad_hook = None                 # callable(layer index): that layer's gradients are final (data parallel)
+        self.shards = None                    # parallel.ShardedFlatState in FULL_SHARD mode (enter_full_shard)
+        self._lw = self._lq = None            # weights (and fp8 quantisations) of the decoder layer being computed
         self._tb = {}
         # transposed copies for dgrad: the decoder's come from Weights(keep_transposed=True); the connector's are made here
         self.conn_t = {}
         self.refresh_transposed(decoder=self.fp8)
+
+    # ------------------------------------------------------------------ FULL_SHARD (fsdp.yaml:11) for the decoder weights
+    def enter_full_shard(self, shards):
+        """Called by ``parallel.attach_data_parallel``: from here on the decoder layers' weights exist on this rank as 1/world
+        slices only.  Per layer and pass ``_enter`` has the layer gathered (the next one already on its way), and derives what
+        that pass needs on the spot: the W^T copies for dgrad (bf16 path; one set of buffers - the per-layer copies kept by
+        ``Weights(keep_transposed=True)`` are released) or the MX-fp8 quantisations (row-wise for the forward, transposed for
+        dgrad).  That is the same derivation work ``refresh_transposed`` does once per step for the replicated layout, moved
+        to where the gathered layer is."""
+        self.shards = shards
+        self.flat.layer_grad_provider = shards.layer_grads
+        self.bb.store = shards                          # evaluation forward (Backbone.layer_weights) reads through the same gathers
+        self.bb.store_t = None
+        for lw in self.w.layers:
+            for k in ("wqkv_t", "wo_t", "wgu_t", "wdown_t"):
+                if k in lw:
+                    lw[k] = None
+        self.wq = {}
+        self._tpool = {}
+
+    MATS = ("wqkv", "wo", "wgu", "wdown")
+
+    def _enter(self, li: int, backward: bool) -> dict:
+        """Weights of decoder layer li for this pass -> ``self._lw`` (and ``self._lq`` on the fp8 path)."""
+        if self.shards is None:
+            self._lw = self.w.layers[li]
+            self._lq = {k: self.wq[(li, k)] for k in self.MATS + tuple(m + "_t" for m in self.MATS)} if self.fp8 else None
+            return self._lw
+        L = self.g.layers
+        nxt = li - 1 if backward else min(li + 1, L - 1)          # (the last forward layer is the first of the backward)
+        lw = self.flat.layer_views(self.shards.layer_weights(li, then=nxt if nxt >= 0 else None), li)
+        lq = {} if self.fp8 else None
+        for k in self.MATS:
+            N, K = lw[k].shape
+            if self.fp8:
+                if backward:
+                    q = self._pool(("qt", k), (K, N), torch.uint8), self._pool(("st", k), (K, N // 32), torch.uint8)
+                    lq[k + "_t"] = ops.transpose_quantize_mxfp8(lw[k], q[0], q[1], N)
+                else:
+                    q = self._pool(("q", k), (N, K), torch.uint8), self._pool(("s", k), (N, K // 32), torch.uint8)
+                    lq[k] = ops.quantize_mxfp8(lw[k], q[0], q[1])
+            elif backward:
+                t = self._pool(("t", k), (K, N), BF16)
+                self._wt(lw[k], t)
+                lw[k + "_t"] = t
+        self._lw, self._lq = lw, lq
+        return lw
+
+    def _pool(self, key, shape, dtype):
+        t = self._tpool.get(key)
+        if t is None:
+            t = self._tpool[key] = torch.empty(shape, dtype=dtype, device=self.dev)
+        return t
 
     # ------------------------------------------------------------------ derived layouts
     def _conn_linears(self):
@@ -167,11 +256,13 @@ class FullFineTune:
             if name not in self.conn_t:
                 self.conn_t[name] = torch.empty(C, R, dtype=BF16, device=self.dev)
             self._wt(wt, self.conn_t[name])
+        if self.shards is not None:           # FULL_SHARD: the decoder's derived layouts are made per gathered layer (_enter)
+            decoder = False
         if decoder and not self.fp8:          # (the fp8 path quantises W^T straight from W below)
             for lw in self.w.layers:
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     self._wt(lw[k], lw[k + "_t"])
-        if self.fp8:      # quantised W for the forward, quantised W^T (straight from W, one pass) for dgrad
+        if self.fp8 and self.shards is None:  # quantised W for the forward, quantised W^T (straight from W, one pass) for dgrad
             for li, lw in enumerate(self.w.layers):
                 for k in ("wqkv", "wo", "wgu", "wdown"):
                     N, K = lw[k].shape
@@ -244,9 +335,9 @@ class FullFineTune:
         of x when its producer already emitted them (rmsnorm_mxfp8 / swiglu_mxfp8 / quantize_dual_mxfp8)."""
         if self.fp8:
             xq, xs = ops.quantize_mxfp8(x) if xq is None else xq
-            wq, ws = self.wq[(li, key)]
+            wq, ws = self._lq[key]
             return ops.gemm_mxfp8(xq, xs, wq, ws, residual=residual)
-        return ops.gemm(x, self.w.layers[li][key], residual=residual)
+        return ops.gemm(x, self._lw[key], residual=residual)
 
     def _norm(self, x, wn):
         """(h, quantised h or None): RMSNorm; on the fp8 path the kernel emits the MX quantisation of h in the same pass."""
@@ -372,7 +463,8 @@ class FullFineTune:
         pos = None if layout is None else layout.pos
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         self.saved = []
-        for li, lw in enumerate(w.layers):
+        for li in range(g.layers):
+            lw = self._enter(li, backward=False)
             h1, h1q = self._norm(x, lw["in_norm"])
             qkv = self._lin(h1, li, "wqkv", xq=h1q)
             ops.rope_(qkv, w.rope_cos, w.rope_sin, B, S, g.heads + g.kv_heads, g.head_dim, pos=pos)
@@ -403,7 +495,7 @@ class FullFineTune:
         dx = ops.rmsnorm_bwd_full(self.x_last, w.final_norm, dhidden, g.rms_eps, G("norm"))
         delta = torch.empty(B, g.heads, S, dtype=torch.float32, device=self.dev)
         for li in range(g.layers - 1, -1, -1):
-            lw, sv = w.layers[li], self.saved[li]
+            lw, sv = self._enter(li, backward=True), self.saved[li]
             pre = f"layers.{li}"
             # MLP: x3 = x2 + down(silu(gate) * up)
             dq_ = self._dual(dx) or (None, None)               # dx quantised both ways from one read
@@ -470,7 +562,12 @@ class FullFineTune:
         """Trained backbone tensors under their upstream names and layouts, on the host: the fp32 masters, or with
         ``which="grad"`` the bf16 gradients of the last backward (tests compare them with autograd by name)."""
         g, f = self.g, self.flat
-        M = lambda n: f.view(getattr(f, which), n).detach().float().cpu()
+        buf = getattr(f, which)
+        if self.shards is not None and (buf is None or buf.numel() < f.numel):
+            # FULL_SHARD: no standing full-size copy - gathered from the owned slices (a collective: every rank calls this;
+            # "grad" is then the REDUCED gradient of the last step)
+            buf = self.shards.gather_full(which)
+        M = lambda n: f.view(buf, n).detach().float().cpu()
         qd, kd = g.heads * g.head_dim, g.kv_heads * g.head_dim
         sd = {"model.embed_tokens.weight": M("embed_tokens"), "model.norm.weight": M("norm")}
         for li in range(g.layers):

@@ -236,7 +236,11 @@ class VLBLitModule(_Base):
             out += self.lora.named_masters()
         if self.full is not None:       # full fine-tune: every backbone tensor outside the vision tower (kernel layouts)
             f = self.full.flat
-            out += [(f"backbone.{n}", f.view(f.master, n)) for n in f.offsets]
+            if f.master is None:        # FULL_SHARD (parallel.attach_data_parallel): no full-size master; the handles are placeholders
+                cache = self.__dict__.get("_param_cache", {})
+                out += [(f"backbone.{n}", cache[f"backbone.{n}"].data) for n in f.offsets if f"backbone.{n}" in cache]
+            else:
+                out += [(f"backbone.{n}", f.view(f.master, n)) for n in f.offsets]
         return out
 
     def trainable_named_parameters(self):

@@ -63,13 +63,23 @@ class VlbAdamW(torch.optim.Optimizer):
 
     def load_full_state(self, name: str, full, index: int = 0):
         f, sh = self.flats[index], self.shardeds[index]
-        full = full.to(f.master.device)
+        full = full.to(f.compute.device)
         if sh is not None:
             sh.load_full(name, full)
-            if name == "master":
+            if name == "master" and f.master is not None:       # (None: FULL_SHARD keeps no full-size staging copy)
                 f.master.copy_(full)
         else:
             getattr(f, name).copy_(full)
+
+    def compute_from_master(self, index: int):
+        """bf16 weights of store `index` <- its restored fp32 masters (checkpoint resume)."""
+        f, sh = self.flats[index], self.shardeds[index]
+        if sh is not None:
+            sh.compute_from_master()
+        else:
+            chunk = 1 << 28
+            for a in range(0, f.numel, chunk):
+                f.compute[a:a + chunk].copy_(f.master[a:a + chunk])
 
     # ------------------------------------------------------------------ checkpoint surface (torch.optim.Optimizer)
     def state_dict(self):
@@ -103,9 +113,7 @@ class VlbAdamW(torch.optim.Optimizer):
                 self.load_full_state("master", f.master, 0)       # the module's load_state_dict restored the masters
             else:
                 self.load_full_state("master", st["master"], i)
-                chunk = 1 << 28
-                for a in range(0, f.numel, chunk):
-                    f.compute[a:a + chunk].copy_(f.master[a:a + chunk])
+                self.compute_from_master(i)
             self.load_full_state("m", st["m"], i)
             self.load_full_state("v", st["v"], i)
         for fn in self.post_step:

@@ -12,9 +12,10 @@ the MI355X-native equivalent of that config, not a translation of torch FSDP:
   master and both moments exist only for the owned slice) and the refreshed bf16 copies are ALL-GATHERED back.  The
   frozen 7B never enters a gradient collective: with ``use_orig_params`` torch FSDP would reduce-scatter 436 MB per
   layer of zeros.  Loss scaling: each rank backpropagates mse/world and lambda||W||^2/world, so the SUM over ranks is
-  the gradient of the single-process objective on the concatenated batch (penalty counted once).  In FSDP's
-  vocabulary this is ZeRO-2 for the trained bf16 WEIGHTS of the full fine-tune (they stay replicated, 14 GB on a
-  288 GB card; gradients and optimiser state are sharded) and FULL_SHARD for the frozen ones when opted into:
+  the gradient of the single-process objective on the concatenated batch (penalty counted once).  The full
+  fine-tune's backbone store is FULL_SHARD for its trained bf16 WEIGHTS as well (``full_shard=True``, the default:
+  1/world of every decoder layer per rank, a layer gathered for its forward and again for its backward into two
+  rotating buffers; ``VLB_FSDP_STRATEGY=SHARD_GRAD_OP`` keeps them replicated), and so are the frozen ones when opted into:
 * ``ShardedLayerStore`` - the fsdp.yaml-equivalent parameter sharding for the frozen decoder layers:
   each rank keeps 1/world of every layer's flat bf16 weights (436 MB/layer -> 54.5 MB at 8 ranks);
   the full layer is all-gathered into one of two buffers on a side stream, one layer ahead of
@@ -100,15 +101,20 @@ class ShardedFlatState:
 
     NAMES = ("master", "grad", "m", "v")
 
-    def __init__(self, flat, comm=None, chunks: int = 4, force_collectives: bool = False):
+    def __init__(self, flat, comm=None, chunks: int = 4, force_collectives: bool = False, full_shard: bool = False):
         """``force_collectives``: run the collective path (separate shard buffers, reduce-scatter / all-gather calls)
-        even at world size 1 - rehearses the RCCL calls on a one-GPU box."""
+        even at world size 1 - rehearses the RCCL calls on a one-GPU box.
+
+        ``full_shard`` (the full fine-tune's backbone store only): ``fsdp_sharding_strategy: FULL_SHARD``
+        (reference fsdp.yaml:11) for the trained bf16 WEIGHTS as well - see ``_enter_full_shard``."""
         self.flat = flat
         self.comm = comm if comm is not None else TorchComm()
         w, r = self.comm.world, self.comm.rank
         self.world, self.rank = w, r
         segs = [flat.head_range]
         L = len(flat.layer_ranges)
+        if full_shard:
+            chunks = max(L, 1)                    # one segment per decoder layer: the unit of every gather and reduce
         per = max(1, -(-L // chunks)) if L else 1
         self.layer_seg = {}                       # first layer of a chunk -> segment index
         for lo in range(0, L, per):
@@ -139,6 +145,70 @@ class ShardedFlatState:
             self.load_masters()
             flat.m = flat.v = None                # the full-size moments are released: sharded state only
         self._pending = {}
+        self.full_shard = bool(full_shard and self.active)
+        if self.full_shard:
+            self._enter_full_shard()
+
+    # ---- FULL_SHARD for trained weights (fsdp.yaml:11; the full fine-tune's backbone store)
+    def _enter_full_shard(self):
+        """Between uses a rank holds only its 1/world slice of every decoder layer's trained bf16 weights (``self.compute``,
+        the buffer AdamW writes) and of their gradients (``self.grad``).  The full-size ``flat.compute`` / ``flat.grad`` /
+        ``flat.master`` are cut down to the TAIL segment (connector, embeddings, final norm: the root unit, gathered for the
+        whole step like FSDP's root module), and two layer-sized weight buffers + two layer-sized gradient buffers take the
+        place of the 32 layers: ``layer_weights(li)`` all-gathers layer li into buffer li % 2 (the next layer's gather is
+        started first so it runs under this layer's kernels: fsdp_forward_prefetch / BACKWARD_PRE), ``layer_grads(li)``
+        hands out the gradient buffer the backward writes, and ``on_layer_done(li)`` reduce-scatters it into the owned
+        slice.  The alignment pads inside a layer stay zero (buffers zeroed once; the kernels write whole tensors only)."""
+        flat, dev = self.flat, self.flat.compute.device
+        assert flat.head_range[0] == 0 and len(self.segments) == len(flat.layer_ranges) + 1
+        self.load_full("compute", flat.compute)               # owned bf16 slices <- the (already synchronised) full weights
+        maxlayer = max(e - s for s, e in flat.layer_ranges)
+        flat.release_layers()                                  # tail-only compute / grad, master released, layer views dropped
+        self.wpool = [torch.zeros(maxlayer, dtype=self.compute.dtype, device=dev) for _ in range(2)]
+        self.gpool = [torch.zeros(maxlayer, dtype=self.grad.dtype, device=dev) for _ in range(2)]
+        self._in_w = [None, None]                 # layer currently (being) gathered into each weight buffer
+        self._w_work = [None, None]
+        torch.cuda.empty_cache()
+
+    def _start_gather(self, li: int):
+        b = li % 2
+        if self._in_w[b] == li:
+            return
+        s, e = self.segments[li + 1]
+        # (the collective is ordered after everything already enqueued on the current stream: the buffer's previous reader)
+        self._w_work[b] = self.comm.all_gather(self.wpool[b][:e - s], self.compute[self._own(li + 1)[1]])
+        self._in_w[b] = li
+
+    def layer_weights(self, li: int, then: int | None = None):
+        """Flat bf16 weights of decoder layer li, gathered (views: ``flat.layer_views``).  ``then``: the layer needed next -
+        its gather is started now, into the other buffer."""
+        self._start_gather(li)
+        b = li % 2
+        if self._w_work[b] is not None:
+            self._w_work[b].wait()
+            self._w_work[b] = None
+        if then is not None and 0 <= then < len(self.flat.layer_ranges) and then % 2 != b:
+            self._start_gather(then)
+        s, e = self.segments[li + 1]
+        return self.wpool[b][:e - s]
+
+    def layer_grads(self, li: int):
+        """The buffer layer li's backward writes its gradients into (the reduce-scatter of the layer that used it last is
+        waited for first)."""
+        b = li % 2
+        prev = self._pending.get(li + 2 + 1)
+        if prev is not None:
+            prev.wait()
+        s, e = self.segments[li + 1]
+        return self.gpool[b][:e - s]
+
+    # the backbone.layer_weights() store interface (validation / inference forward through the frozen-path code)
+    def get(self, li: int) -> dict:
+        return self.flat.layer_views(self.layer_weights(li), li)
+
+    def prefetch(self, li: int):
+        if 0 <= li < len(self.flat.layer_ranges):
+            self._start_gather(li)
 
     def _own(self, si):
         """(slice of the flat buffers this rank owns in segment si, its slice of the shard buffers)."""
@@ -153,7 +223,8 @@ class ShardedFlatState:
             return
         s, e = self.segments[si]
         _, mine = self._own(si)
-        self._pending[si] = self.comm.reduce_scatter(self.grad[mine], self.flat.grad[s:e])
+        src = self.gpool[(si - 1) % 2][:e - s] if (self.full_shard and si > 0) else self.flat.grad[s:e]
+        self._pending[si] = self.comm.reduce_scatter(self.grad[mine], src)
 
     def on_layer_done(self, li: int):
         """LoRA / full backward hook: layer li (walking L-1 .. 0) has its final gradients."""
@@ -177,6 +248,13 @@ class ShardedFlatState:
         """After the update: every rank's refreshed bf16 slices -> the full compute buffer the kernels read."""
         if not self.active:
             return
+        if self.full_shard:          # only the tail is held gathered; the layers' buffers are stale now, layer 0 is fetched ahead
+            s, e = self.segments[0]
+            self.comm.all_gather(self.flat.compute[s:e], self.compute[self._own(0)[1]]).wait()
+            self._in_w, self._w_work = [None, None], [None, None]
+            if len(self.segments) > 1:
+                self._start_gather(0)
+            return
         works = []
         for si, (s, e) in enumerate(self.segments):
             works.append(self.comm.all_gather(self.flat.compute[s:e], self.compute[self._own(si)[1]]))
@@ -195,8 +273,29 @@ class ShardedFlatState:
         return out
 
     def gather_masters(self):
-        if self.active:
+        """Refresh the full-size fp32 staging copy ``flat.master`` (checkpoints, tests).  Under FULL_SHARD there is no
+        standing one: it is created here and dropped again by ``release_staging()``."""
+        if not self.active:
+            return
+        if self.full_shard:
+            self.flat.master = self.gather_full("master")
+        else:
             self.flat.master.copy_(self.gather_full("master"))
+
+    def release_staging(self):
+        if self.full_shard:
+            self.flat.master = None
+
+    def compute_from_master(self):
+        """bf16 weights <- fp32 masters after a restore (checkpoint resume)."""
+        if self.full_shard:
+            self.compute.copy_(self.master)
+            self.gather_compute()
+        else:
+            f = self.flat
+            step = 1 << 28
+            for a in range(0, f.numel, step):
+                f.compute[a:a + step].copy_(f.master[a:a + step])
 
     def load_full(self, name: str, full):
         if not self.active:
@@ -209,12 +308,27 @@ class ShardedFlatState:
 
     def load_masters(self):
         """Owned master slices <- flat.master (after a checkpoint load / broadcast wrote the full buffer)."""
-        if self.active:
+        if self.active and self.flat.master is not None:
             self.load_full("master", self.flat.master)
 
 
-def attach_data_parallel(module, optimizer, group=None, comm=None, force_collectives: bool = False):
-    """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism with sharded optimiser state."""
+def full_shard_default() -> bool:
+    """``fsdp_sharding_strategy`` for the TRAINED backbone weights of the full fine-tune: FULL_SHARD, what the reference's
+    fsdp.yaml:11 says, unless ``VLB_FSDP_STRATEGY=SHARD_GRAD_OP`` keeps them replicated (ZeRO-2: no per-layer weight
+    gathers; 28 GB more per rank at 7B, which a 288 GB card has)."""
+    v = os.environ.get("VLB_FSDP_STRATEGY", "FULL_SHARD").upper()
+    if v not in ("FULL_SHARD", "SHARD_GRAD_OP"):
+        raise ValueError(f"VLB_FSDP_STRATEGY={v!r}: FULL_SHARD or SHARD_GRAD_OP")
+    return v == "FULL_SHARD"
+
+
+def attach_data_parallel(module, optimizer, group=None, comm=None, force_collectives: bool = False, full_shard: bool | None = None,
+                         src: int = 0):
+    """Wire a VLBLitModule + VlbAdamW for clip-sharded data parallelism with sharded optimiser state.
+
+    Full fine-tune: ``full_shard`` (default: ``full_shard_default()``) shards the trained decoder weights 1/world per layer
+    as well.  Because a rank then no longer holds whole weights, the fsdp_sync_module_states broadcast from rank ``src``
+    (fsdp.yaml:13) happens HERE, before the layers are cut up; ``sync_module_states`` afterwards covers the rest."""
     if comm is None:
         comm = make_comm(group)
     state = ShardedFlatState(module.flat, comm, force_collectives=force_collectives)
@@ -224,9 +338,19 @@ def attach_data_parallel(module, optimizer, group=None, comm=None, force_collect
         lora.grad_hook = state.on_layer_done
     module.sharded_backbone = None
     if full is not None:            # full fine-tune: the backbone store is sharded the same way (bf16 gradients)
-        sb = module.sharded_backbone = ShardedFlatState(full.flat, comm, force_collectives=force_collectives)
+        fs = full_shard_default() if full_shard is None else bool(full_shard)
+        if fs:
+            _sync_backbone_store(full, src, group)
+        sb = module.sharded_backbone = ShardedFlatState(full.flat, comm, force_collectives=force_collectives, full_shard=fs)
         optimizer.attach_sharded(sb)
         full.grad_hook = sb.on_layer_done
+        if sb.full_shard:
+            full.enter_full_shard(sb)
+            empty = torch.empty(0, dtype=torch.float32, device=sb.master.device)
+            for n, p_ in zip(optimizer.names, optimizer.param_groups[0]["params"]):
+                if n.startswith("backbone."):
+                    p_.data = empty            # the optimiser's handles were views of the released full-size master
+            torch.cuda.empty_cache()
     module.world_size, module.rank = state.world, state.rank
     module.sharded = state
     return state
@@ -263,6 +387,14 @@ def broadcast_parameters(tensors, src: int = 0, group=None):
             dist.broadcast(t, src=src, group=group)
 
 
+def _sync_backbone_store(full, src: int = 0, group=None):
+    """Rank `src`'s trained backbone weights everywhere (bf16; the fp32 masters are their exact widening)."""
+    broadcast_parameters([full.flat.compute], src, group)
+    step = 1 << 28
+    for a in range(0, full.flat.numel, step):
+        full.flat.master[a:a + step].copy_(full.flat.compute[a:a + step])
+
+
 def sync_module_states(module, src: int = 0, group=None):
     """Broadcast the trainable masters from rank `src` and rebuild everything derived from them on this rank:
     the bf16 compute copies and (LoRA) the transposed / padded adapter layouts the kernels read."""
@@ -274,13 +406,11 @@ def sync_module_states(module, src: int = 0, group=None):
         if sharded is not None:
             sharded.load_masters()
         full = getattr(module, "full", None)
-        if full is not None:
-            broadcast_parameters([full.flat.compute], src, group)      # bf16 weights; masters are their exact widening
-            step = 1 << 28
-            for a in range(0, full.flat.numel, step):
-                full.flat.master[a:a + step].copy_(full.flat.compute[a:a + step])
-            if getattr(module, "sharded_backbone", None) is not None:
-                module.sharded_backbone.load_masters()
+        sb = getattr(module, "sharded_backbone", None)
+        if full is not None and not (sb is not None and sb.full_shard):       # (FULL_SHARD: done by attach_data_parallel)
+            _sync_backbone_store(full, src, group)
+            if sb is not None:
+                sb.load_masters()
             full.refresh_transposed()
     else:
         broadcast_parameters([p.data for p in module.parameters()], src, group)

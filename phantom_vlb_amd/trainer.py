@@ -57,23 +57,28 @@ def trainable_state(module, step: int, to_host: bool = True) -> dict | None:
     ``to_host=False`` (every rank but the writer): take part in the gathers, build nothing, return None - the host
     copies of a 7B full fine-tune's master and moments are 84 GB and only rank 0 writes the file."""
     opt = getattr(module, "optimizer", None)
-    for sh in (getattr(module, "sharded", None), getattr(module, "sharded_backbone", None)):
-        if sh is not None:
-            sh.gather_masters()            # the optimiser updates the owned slices only: refresh the full-size masters
+    shs = [sh for sh in (getattr(module, "sharded", None), getattr(module, "sharded_backbone", None)) if sh is not None]
+    for sh in shs:
+        sh.gather_masters()                # the optimiser updates the owned slices only: refresh the full-size masters
     n_stores = len(opt.flats) if opt is not None else 0
 
     def gathered(name, i=0):
-        t = opt.full_state(name, i)          # collective under data parallelism
+        staged = opt.flats[i].master if name == "master" and opt.shardeds[i] is not None else None
+        t = staged if staged is not None else opt.full_state(name, i)          # collective under data parallelism
         return t.cpu() if to_host else None
 
     state = {}
-    if opt is not None:
-        state.update(exp_avg=gathered("m"), exp_avg_sq=gathered("v"))
-        # further flat stores (full fine-tune: the backbone in kernel layouts) travel whole: master + both moments
-        state["stores"] = [{k: gathered(k, i) for k in ("master", "m", "v")} for i in range(1, n_stores)]
-    if not to_host:
-        return None
-    state.update(state_dict=module.trainable_state_dict(), global_step=step, format=2)
+    try:
+        if opt is not None:
+            state.update(exp_avg=gathered("m"), exp_avg_sq=gathered("v"))
+            # further flat stores (full fine-tune: the backbone in kernel layouts) travel whole: master + both moments
+            state["stores"] = [{k: gathered(k, i) for k in ("master", "m", "v")} for i in range(1, n_stores)]
+        if not to_host:
+            return None
+        state.update(state_dict=module.trainable_state_dict(), global_step=step, format=2)
+    finally:
+        for sh in shs:
+            sh.release_staging()           # FULL_SHARD keeps no standing full-size master
     if opt is not None:
         state.update(opt_step=opt.step_count, flat_offsets={n: (o, k) for n, (o, k, _) in module.flat.offsets.items()},
                      lr=opt.param_groups[0]["lr"])
@@ -139,10 +144,7 @@ def load_trainable_checkpoint(module, path):
         for i, store in enumerate(st.get("stores", []), start=1):
             for k in ("master", "m", "v"):
                 opt.load_full_state(k, store[k], i)
-            f = opt.flats[i]
-            step = 1 << 28
-            for a in range(0, f.numel, step):
-                f.compute[a:a + step].copy_(f.master[a:a + step])
+            opt.compute_from_master(i)
         for fn in opt.post_step:
             fn()                          # derived layouts (LoRA A^T / B pads, W^T copies) from the restored weights
     sch = getattr(module, "scheduler", None)

@@ -91,6 +91,80 @@ def test_sharded_flat_state_reduce_scatter_update_all_gather():
     assert torch.equal(out[0][2], out[1][2])
 
 
+class _FakeFullShardFlat(_FakeFlat):
+    """+ the two methods parallel.ShardedFlatState._enter_full_shard asks of fullft.FlatBackbone."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.grad = torch.zeros(self.numel, dtype=torch.bfloat16)
+
+    def release_layers(self):
+        T = self.head_range[1]
+        self.compute, self.grad, self.master = self.compute[:T].clone(), torch.zeros(T, dtype=torch.bfloat16), None
+
+    def layer_views(self, buf, li):
+        return {"w": buf}
+
+
+def _full_shard_state(rank, world):
+    """fsdp.yaml:11 FULL_SHARD for trained weights, the host logic on CPU tensors: after the state is attached a rank holds its
+    half of every layer + the tail; layer_weights() gathers a layer into one of two buffers (the next one started ahead, in both
+    walking directions), the backward's gradients go through two rotating layer buffers into the owned slices, the update's
+    refreshed slices come back through the per-layer gathers."""
+    from phantom_vlb_amd.parallel import ShardedFlatState
+    flat = _FakeFullShardFlat()
+    L, (T0, T1) = len(flat.layer_ranges), flat.head_range
+    full_w = flat.compute.clone()
+    st = ShardedFlatState(flat, full_shard=True)
+    assert st.full_shard and len(st.segments) == L + 1 and st.layer_seg == {i: i + 1 for i in range(L)}
+    assert flat.master is None and flat.compute.numel() == T1 and flat.grad.numel() == T1
+    assert st.compute.numel() * world == full_w.numel() and len(st.wpool) == 2 and len(st.gpool) == 2
+    ok = True
+    for li in list(range(L)) + list(range(L - 1, -1, -1)):                    # forward order, then backward order
+        nxt = li + 1 if li + 1 < L else None
+        s, e = flat.layer_ranges[li]
+        ok &= bool(torch.equal(st.layer_weights(li, then=nxt), full_w[s:e]))
+    ok &= bool(torch.equal(st.get(1)["w"], full_w[slice(*flat.layer_ranges[1])]))
+    # backward: every rank writes its own gradient of layer li into the buffer it is handed, then reports the layer done
+    gens = [torch.Generator().manual_seed(500 + r) for r in range(world)]
+    grads = [torch.randn(full_w.numel(), generator=g_).bfloat16() for g_ in gens]          # what each rank "computes"
+    for li in range(L - 1, -1, -1):
+        s, e = flat.layer_ranges[li]
+        st.layer_grads(li).copy_(grads[rank][s:e])
+        st.on_layer_done(li)
+    flat.grad.copy_(grads[rank][T0:T1])
+    st.finish_reduce()
+    total = sum(g_.float() for g_ in grads)
+    for si in range(L + 1):
+        whole, mine = st._own(si)
+        ok &= bool(torch.allclose(st.grad[mine].float(), total[whole], atol=0.05, rtol=0.02))
+    # "optimiser": a slice-local update, then the tail is gathered and the layers come back layer by layer
+    st.master.sub_(0.5 * st.grad.float())
+    st.compute.copy_(st.master)
+    st.gather_compute()
+    want = st.gather_full("compute")
+    ok &= bool(torch.equal(flat.compute, want[T0:T1]))
+    for li in range(L):
+        s, e = flat.layer_ranges[li]
+        ok &= bool(torch.equal(st.layer_weights(li, then=li + 1), want[s:e]))
+    ok &= bool((want[flat.layer_ranges[0][0]:].float() != full_w[flat.layer_ranges[0][0]:].float()).any())
+    # staging copy for a checkpoint, dropped again; masters restored from a full-size copy
+    st.gather_masters()
+    staged = flat.master.clone()
+    st.release_staging()
+    ok &= flat.master is None and staged.numel() == full_w.numel()
+    st.master.zero_()
+    st.load_full("master", staged)
+    st.compute_from_master()
+    ok &= bool(torch.equal(st.gather_full("compute"), want))
+    return bool(ok)
+
+
+def test_full_shard_state_gathers_layers_and_reduces_through_rotating_buffers():
+    ret = _run(_full_shard_state)
+    assert ret[0] and ret[1]
+
+
 def test_sharded_flat_state_world_one_aliases_the_flat_buffers():
     from phantom_vlb_amd.parallel import ShardedFlatState
     flat = _FakeFlat()

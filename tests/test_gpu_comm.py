@@ -58,6 +58,53 @@ def test_sharded_step_through_direct_comm_equals_plain_step(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_full_shard_step_through_direct_comm_equals_plain_step(dev, fp8):
+    """fsdp.yaml:11 FULL_SHARD of the TRAINED decoder weights with the RCCL calls in the loop (libvlb's communicator at
+    world 1, ``force_collectives``): per-layer all-gathers into the two rotating buffers, W^T (bf16) / MX quantisations (fp8)
+    derived per gathered layer, gradients reduce-scattered out of the rotating gradient buffers.  At world 1 every
+    collective is an identity, so three optimiser steps must leave BIT-identical masters, moments and bf16 weights to the
+    plain single-process run that keeps everything resident."""
+    import dataclasses
+    import vlb_oracle as O
+    from phantom_vlb_amd.litmodule import VLBLitModule, VLBLitModuleConfig
+    from phantom_vlb_amd.parallel import attach_data_parallel
+    from phantom_vlb_amd.parallel_native import DirectComm
+    cfg = VLBLitModuleConfig(model_path="none", freeze_backbone=False, use_lora=False, lora_r=None, lora_alpha=None, lora_dropout=None,
+                             dropout_rate=0.1, num_target=128, l2_lambda=1e-3, lr=1e-3, betas=[0.9, 0.999], eps=1e-8,
+                             weight_decay=1e-2, lr_scheduler_name="CosineAnnealingLR", last_epoch=-1, t_max=50000, geometry="mini",
+                             fp8_gemm=fp8)
+    g = O.geometry_mini()
+    p = O.round_bf16(O.init_params(g, seed=3))
+    batch = O.synthetic_batch(g, 4, seed=4)
+    outs = []
+    for shard in (False, True):
+        m = VLBLitModule(cfg)
+        m.configure_model(state_dict=p)
+        opt, _ = m.configure_optimizers()
+        sb = None
+        if shard:
+            attach_data_parallel(m, opt[0], comm=DirectComm(), force_collectives=True, full_shard=True)
+            sb = m.sharded_backbone
+            assert sb.full_shard and m.full.flat.master is None and m.backbone.w.layers[0]["wqkv"] is None
+        losses = []
+        for _ in range(3):
+            losses.append(float(m.training_step(batch)))
+            opt[0].step()
+        val = m.validation_step(batch)
+        torch.cuda.synchronize()
+        if shard:
+            outs.append((sb.gather_full("master"), sb.gather_full("compute"), sb.gather_full("m"), sb.gather_full("v"), losses, val))
+        else:
+            f = m.full.flat
+            outs.append((f.master.clone(), f.compute.clone(), f.m.clone(), f.v.clone(), losses, val))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == outs[1][4]
+    va, vb = outs[0][5], outs[1][5]
+    assert float(va["loss"] if isinstance(va, dict) else va) == float(vb["loss"] if isinstance(vb, dict) else vb)
+
+
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_direct_schedules_on_the_loopback_transport(dev, world):
     """The all-pairs exchange code of vlb_allgather_direct / vlb_reducescatter_direct(_bf16) / vlb_allreduce_scalar - peer

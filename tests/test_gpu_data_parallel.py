@@ -95,7 +95,7 @@ def test_two_rank_lora_with_sharded_frozen_weights(dev):
     assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
 
 
-def _worker_full(rank, world, port, ret):
+def _worker_full(rank, world, port, ret, full_shard=False, fp8=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
@@ -109,7 +109,7 @@ def _worker_full(rank, world, port, ret):
         g = O.geometry_mini()
         p = O.round_bf16(O.init_params(g, seed=3))
         full = O.synthetic_batch(g, 4, seed=4)
-        cfg = dataclasses.replace(_cfg(False), freeze_backbone=False)
+        cfg = dataclasses.replace(_cfg(False), freeze_backbone=False, fp8_gemm=fp8)
 
         def build():
             m = VLBLitModule(cfg)
@@ -117,24 +117,50 @@ def _worker_full(rank, world, port, ret):
             opt, _ = m.configure_optimizers()
             return m, opt[0]
         m, opt = build()
-        st = attach_data_parallel(m, opt)
+        numel = m.full.flat.numel
+        st = attach_data_parallel(m, opt, full_shard=full_shard)
         sb = m.sharded_backbone
-        assert sb is not None and sb.active and sb.numel * 2 == m.full.flat.numel and sb.grad.dtype == torch.bfloat16
+        assert sb is not None and sb.active and sb.numel * 2 == numel and sb.grad.dtype == torch.bfloat16
+        assert sb.full_shard == full_shard
         sync_module_states(m)
         mine = {k: v[rank * 2:rank * 2 + 2] for k, v in full.items()}
+        if full_shard:
+            # fsdp.yaml:11 FULL_SHARD: between uses this rank holds half of every layer and the tail segment only
+            f = m.full.flat
+            T = f.head_range[1]
+            assert f.master is None and f.compute.numel() == T and f.grad.numel() == T and f.numel == numel
+            assert all(m.backbone.w.layers[li][k] is None for li in range(g.layers) for k in ("wqkv", "wo", "wgu", "wdown", "in_norm"))
+            assert all(lw.get(k) is None for lw in m.backbone.w.layers for k in ("wqkv_t", "wdown_t")) and not m.full.wq
+            held = sb.compute.numel() + sum(b.numel() for b in sb.wpool)         # bf16 weight elements resident on this rank
+            layer = max(e - s for s, e in f.layer_ranges)
+            assert held == numel // 2 + 2 * layer
+            assert all(p_.numel() == 0 for n, p_ in zip(opt.names, opt.param_groups[0]["params"]) if n.startswith("backbone."))
+            with pytest.raises(RuntimeError, match="tail segment only"):
+                f.view(f.compute, "layers.1.wdown")
         m.training_step(mine)
         opt.step()
         g_dp = sb.gather_full("grad").float()
         sb.gather_masters()
         torch.cuda.synchronize()
-        out = {"master": m.full.flat.master.cpu(), "compute": m.full.flat.compute.float().cpu(),
-               "wt_ok": bool(torch.equal(m.backbone.w.layers[1]["wdown_t"], m.backbone.w.layers[1]["wdown"].t()))}
+        if full_shard:
+            out = {"master": m.full.flat.master.cpu(), "compute": sb.gather_full("compute").float().cpu(), "wt_ok": True}
+            sb.release_staging()
+            assert m.full.flat.master is None
+            # the evaluation forward reads the layers through the same gathers (Backbone.layer_weights -> sb.get / prefetch)
+            v = m.validation_step(mine)
+            torch.cuda.synchronize()
+            out["val_ok"] = bool(torch.isfinite(torch.as_tensor(float(v["loss"] if isinstance(v, dict) else v))))
+        else:
+            out = {"master": m.full.flat.master.cpu(), "compute": m.full.flat.compute.float().cpu(),
+                   "wt_ok": bool(torch.equal(m.backbone.w.layers[1]["wdown_t"], m.backbone.w.layers[1]["wdown"].t()))}
         # checkpoint state under data-parallel full fine-tuning: the upstream-named state_dict must hold the UPDATED backbone
         # weights (the optimiser writes the shard buffers; trainable_state gathers them first), it must agree with the flat
         # `stores` copy, and only the writing rank builds host copies
         from phantom_vlb_amd.trainer import trainable_state
-        m.full.flat.master.zero_()                      # stale staging area: whatever survives must come from the shards
+        if not full_shard:
+            m.full.flat.master.zero_()                  # stale staging area: whatever survives must come from the shards
         state = trainable_state(m, 1, to_host=rank == 0)
+        assert not full_shard or m.full.flat.master is None          # no standing 4 B/param copy after the checkpoint either
         if rank == 0:
             f = m.full.flat
             store = state["stores"][0]["master"]
@@ -152,7 +178,25 @@ def _worker_full(rank, world, port, ret):
             ropt.step()
             torch.cuda.synchronize()
             out["cos"] = float((g_dp * g_ref).sum() / (g_dp.norm() * g_ref.norm()))
-            out["perr"] = float((m.full.flat.master - ref.full.flat.master).abs().max())
+            out["perr"] = float((out["master"].to(ref.full.flat.master.device) - ref.full.flat.master).abs().max())
+        if full_shard:
+            # a second step: the refreshed slices are gathered again layer by layer, then the checkpoint is restored and the
+            # step replayed - the resumed run lands on the same weights (collectives: both ranks)
+            if rank == 0:
+                ref.training_step(full)
+                ropt.step()
+            m.training_step(mine)
+            opt.step()
+            after2 = sb.gather_full("master").cpu()
+            if rank == 0:
+                torch.cuda.synchronize()
+                out["perr2"] = float((after2.to(ref.full.flat.master.device) - ref.full.flat.master).abs().max())
+            store = [state["stores"][0]] if rank == 0 else [None]
+            dist.broadcast_object_list(store, src=0)
+            for k in ("master", "m", "v"):
+                opt.load_full_state(k, store[0][k], 1)
+            opt.compute_from_master(1)
+            out["restored"] = bool(torch.equal(sb.gather_full("master").cpu(), out["master"]))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -170,6 +214,24 @@ def test_two_rank_full_finetune_matches_single_process(dev):
     assert ret[0]["perr"] < 2.5e-3
     assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
     assert ret[0]["wt_ok"] and ret[1]["wt_ok"]
+    assert ret[0]["ckpt_ok"] and ret[0]["ckpt_moved"] and ret[0]["ckpt_master"] and ret[1]["ckpt_none"]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_two_rank_full_shard_finetune_matches_single_process(dev, fp8):
+    """fsdp.yaml:11 ``FULL_SHARD`` for the TRAINED weights (configs[4]'s layout in miniature): each rank keeps half of every
+    decoder layer's bf16 weights, gradients, masters and moments; a layer is all-gathered into one of two buffers for its
+    forward and again for its backward (W^T / MX-fp8 quantisations derived from the gathered layer), its gradients are
+    reduce-scattered out of one of two layer-sized buffers.  Same numbers as the replicated-weights layout, a second step on
+    re-gathered weights, evaluation forward through the gathers, checkpoint + restore."""
+    import random
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_full, args=(2, 29600 + random.randint(0, 2000), ret, True, fp8), nprocs=2, join=True)
+    assert ret[0]["cos"] > (0.97 if fp8 else 0.995), ret[0]["cos"]
+    assert ret[0]["perr"] < 2.5e-3 and ret[0]["perr2"] < 5e-3, (ret[0]["perr"], ret[0]["perr2"])
+    assert torch.equal(ret[0]["master"], ret[1]["master"]) and torch.equal(ret[0]["compute"], ret[1]["compute"])
+    assert ret[0]["val_ok"] and ret[1]["val_ok"] and ret[0]["restored"] and ret[1]["restored"]
     assert ret[0]["ckpt_ok"] and ret[0]["ckpt_moved"] and ret[0]["ckpt_master"] and ret[1]["ckpt_none"]
 
 
