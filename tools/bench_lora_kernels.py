@@ -24,7 +24,7 @@ def timeit(fn, n=20):
 
 
 seeds3 = [11, 22, 33]
-for K, G, p in [(4096, 3, 0.1), (4096, 1, 0.1), (4096, 2, 0.1), (14336, 1, 0.1), (4096, 1, 0.0), (1024, 1, 0.0), (14336, 1, 0.0)]:
+for K, G, p in [(4096, 3, 0.1), (4096, 3, 0.0), (4096, 2, 0.1), (4096, 2, 0.0), (4096, 1, 0.1), (4096, 1, 0.0), (14336, 1, 0.1), (14336, 1, 0.0), (1024, 1, 0.0)]:
     R = 16 * G
     x = torch.randn(M, K, device=dev).to(BF)
     A = (torch.randn(R, K, device=dev) * 0.02).to(BF)
@@ -32,21 +32,21 @@ for K, G, p in [(4096, 3, 0.1), (4096, 1, 0.1), (4096, 2, 0.1), (14336, 1, 0.1),
     dt = timeit(lambda: lora_down(x, A, R, 2.0, p, seeds3[:G], t))
     byt = M * K * 2 + R * K * 2 + M * R * 2
     print(f"lora_down  K={K:5d} G={G} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
-for K, G in [(4096, 3), (4096, 1), (4096, 2), (14336, 1)]:
+for K, G, p in [(4096, 3, 0.1), (4096, 3, 0.0), (4096, 2, 0.1), (4096, 2, 0.0), (4096, 1, 0.1), (4096, 1, 0.0), (14336, 1, 0.1), (14336, 1, 0.0)]:
     R = 16 * G
     u = torch.randn(M, PAD, device=dev).to(BF)
     At = torch.zeros(K, PAD, dtype=BF, device=dev)
     At[:, :R] = (torch.randn(K, R, device=dev) * 0.02).to(BF)
     dx = torch.randn(M, K, device=dev).to(BF)
-    dt = timeit(lambda: lora_dx_masked(u, At, dx, R, 0.1, seeds3[:G]))
+    dt = timeit(lambda: lora_dx_masked(u, At, dx, R, p, seeds3[:G]))
     byt = 2 * M * K * 2 + M * R * 2
-    print(f"lora_dx    K={K:5d} G={G}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
-for K, N, p in [(4096, 48, 0.1), (4096, 16, 0.1), (4096, 32, 0.1), (14336, 16, 0.1), (4096, 16, 0.0), (14336, 16, 0.0), (1024, 16, 0.0)]:
+    print(f"lora_dx    K={K:5d} G={G} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
+for K, N, p in [(4096, 48, 0.1), (4096, 48, 0.0), (4096, 32, 0.1), (4096, 32, 0.0), (4096, 16, 0.1), (4096, 16, 0.0), (14336, 16, 0.1), (14336, 16, 0.0), (1024, 16, 0.0)]:
     Gm = torch.randn(M, PAD, device=dev).to(BF)
     X = torch.randn(M, K, device=dev).to(BF)
     dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.vlb_wgrad_splits(M) * 48 * K, dtype=torch.float32, device=dev)
-    dt = timeit(lambda: wgrad_skinny(Gm, X, dW, ws, N, p=p, seeds=seeds3[:N // 16] if p > 0 else None))
+    dt = timeit(lambda: wgrad_skinny(Gm, X, dW, ws, N, p=p, seeds=seeds3[:N // 16]))
     byt = M * K * 2 + M * N * 2 + N * K * 4
     print(f"wgrad      K={K:5d} N={N} p={p}: {dt*1e6:7.1f} us  {byt/dt/1e12:5.2f} TB/s", flush=True)
 # dB^T + u fused (one pass over dy) vs the lora_down + wgrad pair
