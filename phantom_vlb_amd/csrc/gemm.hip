@@ -9,6 +9,7 @@
 // MFMA operand roles are swapped on purpose (rows of the MFMA = output COLUMNS n, columns of the
 // MFMA = output rows m): each lane then owns 4 consecutive n of one row m per 16x16 tile, so the
 // epilogue packs 4 bf16 into one 8-byte store and bias/residual are 8-byte loads.
+#include <atomic>
 #include <type_traits>
 
 #include "common.hpp"
@@ -43,6 +44,8 @@ struct GemmArgs {
   int stagger;              // tools build only (timing experiment): odd workgroups of the first round start this many 10-ns ticks late
   int wide;                 // C (and aux) rows 16-byte aligned: required by the four-wave kernels, which store 16 bytes per lane (store_pair16)
   int persist_iters;        // tools build only (persistent experiment): output tiles per workgroup, grid = 256
+  // stream-K launch (gemm_w4_kernel<.., STREAMK>): 256 workgroups share sk_total = tiles x K-tiles iterations evenly; see the kernel
+  int sk_total; unsigned long long* sk_flags; unsigned long long sk_want; int* sk_err;
 };
 
 // blockIdx -> (m0, n0).  The order is defined on the full parent grid, so a GEMM can be cut into several launches (full
@@ -707,7 +710,23 @@ __device__ __forceinline__ int w4_epilogue_kind(const GemmArgs& p) {
 // block 96 rows), picked by the host when they quantise the row count into fewer, fuller waves of tiles.
 // MASKED: the second operand pair (one K-tile, K2 = 64) runs FIRST, the accumulators are then multiplied by the
 // dropout keep mask / (1-p) in place, and the main K loop continues on top - dx = dy.W + keep*(u.A)/(1-p) in one GEMM.
-template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false, bool SPLITK = false>
+//
+// STREAMK (instantiated by the tools build only; measured 1.4-2x slower than the round + tail plans, see launch_w4_streamk):
+// ONE launch of 256 workgroups for an output of more than 256 tiles that is not a whole number of rounds.  The
+// launch's work is the sequence of (tile, K-tile) iterations in tile order, tiles x nk of them; workgroup r (= the r-th CU
+// slot of its XCD-contiguous run) takes iterations [bound(r), bound(r+1)) - the same number for everybody, so nobody idles
+// through a mostly empty last round and no second launch re-cuts it.  A range is at least one tile long (tiles >= 256), so a
+// tile is shared by at most two workgroups: the one that holds its FIRST K-tiles (at the END of its own range) owns it, the
+// next workgroup computes the rest of the tile at the START of its range, stores the raw fp32 accumulators as a slab
+// (layout of the split-K tail) and raises the tile's flag; the owner adds the slab to its own accumulators (fixed order:
+// bit-reproducible) and runs the epilogue.  Whole tiles inside a range end in the normal epilogue.  A contributor never
+// waits for anything, and an owner only for the first segment of the workgroup dispatched right after it in the same XCD
+// run, so the launch cannot deadlock however few CUs the dispatcher finds free; the owner's wait is bounded all the same
+// (sk_err is raised and the host fails the next call).  Cross-XCD visibility: slab and flag travel with agent-scope (sc1)
+// stores and loads - the instructions the gfx942 / gfx950 memory model uses for agent-scope atomics - ordered by vmcnt(0) +
+// a workgroup barrier on the writing side and by the flag load + barrier on the reading side; no cache-wide write-back or
+// invalidate (see the contributor branch).
+template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false, bool SPLITK = false, bool STREAMK = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
   constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
@@ -723,14 +742,34 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 
   constexpr bool PERSIST = (ABL & 128) != 0;             // tools: one workgroup per CU streams over persist_iters output tiles (below)
   static_assert(!PERSIST || (!MASKED && !SPLITK && !ROWSPLIT), "persistent stream: plain launches only");
+  static_assert(!STREAMK || (NT == 8 && !SPLITK && !PERSIST && !ROWSPLIT), "stream-K: whole-width tiles, its own K ranges");
+  constexpr bool KRANGE = SPLITK || STREAMK;           // this workgroup walks a sub-range of a tile's K-tiles
+  constexpr int SK_MIN = 4;                             // no stream-K segment shorter than this many K-tiles
   int m0, n0;
   int ksplit = 0;
+  const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
+  const int nk_all = p.K / BK + p.K2 / BK;
+  // stream-K: iteration range of this workgroup.  Boundaries closer than SK_MIN K-tiles to a tile boundary snap onto it
+  // (both neighbours compute the same bound).  XCD x = blockIdx & 7 takes the contiguous ranges [32x, 32x + 32).
+  [[maybe_unused]] int sk_r = 0, sk_it = 0, sk_end = 0;
+  auto sk_bound = [&](int r) {
+    int b = (int)((int64_t)r * p.sk_total / 256);
+    const int rem = b % nk_all;
+    if (rem < SK_MIN) b -= rem; else if (rem > nk_all - SK_MIN) b += nk_all - rem;
+    return b;
+  };
   // persistent stream: work item `it` of workgroup b is tile id it*256 + (b&7)*32 + (b>>3) - the tile a launch of
   // persist_iters*256 workgroups hands to the same CU slot in its round `it` (tile order bit 1)
   auto persist_coords = [&](int it, int& pm0, int& pn0) {
     tile_coords(p, p.tile0 + it * 256 + ((blockIdx.x & 7) << 5) + (blockIdx.x >> 3), 0, BM, BN, pm0, pn0);
   };
   if constexpr (PERSIST) persist_coords(0, m0, n0);
+  else if constexpr (STREAMK) {
+    sk_r = ((blockIdx.x & 7) << 5) + (blockIdx.x >> 3);
+    sk_it = sk_bound(sk_r); sk_end = sk_bound(sk_r + 1);
+    if (sk_it >= sk_end) return;
+    tile_coords(p, p.tile0 + sk_it / nk_all, 0, BM, BN, m0, n0);
+  }
   else ksplit = map_tile(p, BM, BN, m0, n0);
 #ifdef VLB_TOOLS
   // timing experiment: de-synchronise the CUs (every workgroup of a launch otherwise starts, and reaches its epilogue's
@@ -754,12 +793,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int r0 = wave * 8 + srow;
   const int colb = (sslot ^ ((r0 >> 1) & 7)) * 8;
   // (tools build, timing only: ABL bit 4 / 5 make every workgroup stage W / A panel 0 - operands that always hit in L2)
-  int rowA = (ABL & 32) ? r0 : m0 + r0, rowW = (ABL & 16) ? r0 : n0 + r0;       // (re-pointed per output tile by the persistent stream)
-  const int nk1 = MASKED ? p.K2 / BK : p.K / BK;       // K-tiles of the pair that runs first
-  const int nk_all = p.K / BK + p.K2 / BK;
+  int rowA = (ABL & 32) ? r0 : m0 + r0, rowW = (ABL & 16) ? r0 : n0 + r0;       // (re-pointed per output tile by the persistent stream / per stream-K segment)
   // split-K tail: this workgroup walks K-tiles [kt_lo, kt_lo + nk) of the concatenated (pair 1 | pair 2) sequence
-  const int kt_lo = SPLITK ? (int)((int64_t)ksplit * nk_all / p.k_splits) : 0;
-  const int nk = SPLITK ? (int)((int64_t)(ksplit + 1) * nk_all / p.k_splits) - kt_lo : nk_all;
+  int kt_lo = SPLITK ? (int)((int64_t)ksplit * nk_all / p.k_splits) : 0;
+  int nk = SPLITK ? (int)((int64_t)(ksplit + 1) * nk_all / p.k_splits) - kt_lo : nk_all;
+  if constexpr (STREAMK) { kt_lo = sk_it % nk_all; nk = min(nk_all - kt_lo, sk_end - sk_it); }     // first segment (re-set per segment below)
 
   // LDS-DMA sources = uniform base (SGPR pair, advanced 128 B per K-tile) + a per-instruction 32-bit
   // byte offset held in a VGPR: the loop issues each global_load_lds with no address arithmetic at all.
@@ -776,9 +814,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     curW = reinterpret_cast<const char*>(W_) + (int64_t)kt_in_pair * ROW_BYTES;
   };
   auto select = [&](int rel) {          // call with consecutive rel = 0, 1, ..: positions the bases on K-tile kt_lo + rel
-    const int kt = SPLITK ? rel + kt_lo : rel;
+    const int kt = KRANGE ? rel + kt_lo : rel;
     if (rel == 0) {
-      const bool second = SPLITK && kt >= nk1;
+      const bool second = KRANGE && kt >= nk1;
       if (MASKED != second) set_operands(p.A2, p.W2, p.lda2, p.ldw2, second ? kt - nk1 : kt);
       else set_operands(p.A, p.W, p.lda, p.ldw, second ? kt - nk1 : kt);
     }
@@ -821,6 +859,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W4_BARRIER() do { W4_FENCE(); __builtin_amdgcn_s_barrier(); W4_FENCE(); } while (0)
 
+sk_segment: __attribute__((unused));                  // stream-K: every further segment of this workgroup's range re-enters here
   select(0);
 #pragma unroll
   for (int i = 0; i < A_LD + B_LD; ++i) dma(0, i);
@@ -1054,8 +1093,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     // K-tile 0 = the LoRA pair u.A (host guarantees K2 == 64 and nk >= 3); then keep/(1-p) on the accumulators.
     // In a split-K tail only the first K range holds the pair: the others run their first main tile here and the
     // mask degenerates to keep-all x 1.0 (same straight-line code, no branch around the pinned accumulators).
-    const uint32_t m_thresh = (SPLITK && ksplit != 0) ? 0u : p.drop_thresh;
-    const float m_scale = (SPLITK && ksplit != 0) ? 1.f : p.drop_scale;
+    const bool later_range = (SPLITK && ksplit != 0) || (STREAMK && kt_lo != 0);
+    const uint32_t m_thresh = later_range ? 0u : p.drop_thresh;
+    const float m_scale = later_range ? 1.f : p.drop_scale;
     tile(0, T_{}, T_{});
     kt = 1;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -1114,6 +1154,52 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         *reinterpret_cast<f32x4*>(wt + ((i * NT + j) * 64 + lane) * 4) = acc[i][j];
     return;
   }
+#define W4_DONE do { if constexpr (STREAMK) goto sk_next; else return; } while (0)
+  if constexpr (STREAMK) {
+    if (kt_lo != 0) {
+      // contributor: the rest of a tile whose first K-tiles belong to workgroup sk_r - 1.  Slab sk_r, then the flag.
+      float* wt = p.ws + ((int64_t)sk_r * 4 + wave) * (MT * NT * 256);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          *reinterpret_cast<f32x4*>(wt + ((i * NT + j) * 64 + lane) * 4) = acc[i][j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slab stores have reached L2
+      __builtin_amdgcn_s_barrier();                             // ... and so have the other three waves'
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // L2 write-back (buffer_wbl2 sc1): visible to the owner's XCD
+        __hip_atomic_store(p.sk_flags + sk_r, p.sk_want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      goto sk_next;
+    }
+    if (nk < nk_all) {
+      // owner of a tile whose remaining K-tiles are the first segment of workgroup sk_r + 1: wait for its slab (bounded),
+      // add it to the accumulators, then the normal epilogue
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(p.sk_flags + sk_r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_want) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1 << 20)) {                            // ~2 s: never in a healthy launch; results are then wrong and the host is told
+            __hip_atomic_store(p.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // L2 / L1 invalidate (buffer_inv sc1): the slab is read from where the release put it
+      const float* ps = p.ws + ((int64_t)(sk_r + 1) * 4 + wave) * (MT * NT * 256);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ps + ((i * NT + j) * 64 + lane) * 4);
+          f32x4 v = acc[i][j];
+          v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+          acc[i][j] = v;
+          asm volatile("" : "+a"(acc[i][j]));
+        }
+    }
+  }
   // The four-wave kernels store 16 bytes per lane (store_pair16): the host only routes launches here whose C / aux rows are
   // 16-byte aligned (GemmArgs::wide).  One loop nest per epilogue kind - every loop over acc[][] must unroll completely
   // (a dynamically indexed accumulator array is moved to scratch memory, and with it the whole K loop).
@@ -1126,7 +1212,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       for (int j = 0; j < NT; j += 4)
         store_swiglu8(p, acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3], m, (n0 + wn * TN) / 2 + (j / 2) * 16 + fq * 4, fq);
     }
-    return;
+    W4_DONE;
   }
 #define W4_EPILOGUE(KIND)                                                                                              \
   _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                      \
@@ -1135,14 +1221,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     _Pragma("unroll") for (int j = 0; j < NT; j += 2)                                                                   \
       w4_store_frag2<KIND>(p, acc[i][j], acc[i][j + 1], m, n0 + wn * TN + j * 16 + fq * 4, fq);                         \
   }
-  const int kind = w4_epilogue_kind(p);
-  if (kind == EPI_PLAIN) { W4_EPILOGUE(EPI_PLAIN) return; }
-  if (kind == EPI_RESIDUAL) { W4_EPILOGUE(EPI_RESIDUAL) return; }
-  if (kind == EPI_SWIGLU_BWD) { W4_EPILOGUE(EPI_SWIGLU_BWD) return; }
+  {
+    const int kind = w4_epilogue_kind(p);
+    if (kind == EPI_PLAIN) { W4_EPILOGUE(EPI_PLAIN) W4_DONE; }
+    if (kind == EPI_RESIDUAL) { W4_EPILOGUE(EPI_RESIDUAL) W4_DONE; }
+    if (kind == EPI_SWIGLU_BWD) { W4_EPILOGUE(EPI_SWIGLU_BWD) W4_DONE; }
 #define W4_EPILOGUE_ACT(ACT) W4_EPILOGUE(EPI_GENERIC + ACT)
-  VLB_DISPATCH_ACT(p.act, W4_EPILOGUE_ACT);
+    VLB_DISPATCH_ACT(p.act, W4_EPILOGUE_ACT);
 #undef W4_EPILOGUE_ACT
 #undef W4_EPILOGUE
+  }
+sk_next: __attribute__((unused));
+  if constexpr (STREAMK) {
+    sk_it += nk;
+    if (sk_it < sk_end) {
+      // next segment of this workgroup's range: a new tile from its first K-tile (whole, or the head this workgroup owns)
+      tile_coords(p, p.tile0 + sk_it / nk_all, 0, BM, BN, m0, n0);
+      rowA = m0 + r0; rowW = n0 + r0;
+      kt_lo = sk_it % nk_all; nk = min(nk_all - kt_lo, sk_end - sk_it);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
+      asm volatile("s_nop 7" ::: "memory");                // VALU writes of the accumulators settle before the next MFMA reads them
+      goto sk_segment;
+    }
+  }
+#undef W4_DONE
 }
 
 #ifdef VLB_TOOLS
@@ -1418,23 +1523,23 @@ inline int launch_wd(GemmArgs& a, hipStream_t s) {
 }
 #endif
 
-template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
+template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false, bool STREAMK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
 #ifdef VLB_TOOLS
-  if constexpr (NT == 8 && ABL == 0 && MT == 8 && !MASKED && !SPLITK) {
+  if constexpr (NT == 8 && ABL == 0 && MT == 8 && !MASKED && !SPLITK && !STREAMK) {
     if (g_wd && a.split_n == 1 && a.k_splits <= 1) return launch_wd(a, s);
   }
 #endif
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK, STREAMK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
     vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
     return VLB_ERR_LAUNCH;
   }
 #ifdef VLB_TOOLS
-  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK) {
+  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK && !STREAMK) {
     // tools A/B: persistent stream over the full rounds of the launch (the ragged rest as a normal launch)
     const int nk_all = a.K / 64 + a.K2 / 64;
     const bool act_ok = a.act == VLB_ACT_NONE || a.act == VLB_ACT_SWIGLU_PAIR;
@@ -1455,7 +1560,7 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
       return VLB_OK;
     }
   }
-  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK) {
+  if constexpr (ABL == 0 && NT == 8 && !MASKED && !SPLITK && !STREAMK) {
     if (g_w4_rowsplit) {                     // tools A/B: the row-split K loop
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, 64, MT, MASKED, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return VLB_ERR_LAUNCH;
@@ -1465,10 +1570,46 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
   }
 #endif
-  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK, STREAMK>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
+
+#ifdef VLB_TOOLS
+// ---- stream-K launch (see gemm_w4_kernel).  TOOLS BUILD ONLY: built and measured in round 4, 1.4-2x SLOWER than
+// the round + tail plans on every ragged shape of the LoRA step - equal-length iteration ranges put the 256 CUs at different
+// K offsets of their tiles, so the CUs that share an A or W panel no longer read the same K-slice at the same time, the per-XCD
+// L2 stops serving the re-reads, and the launch runs at the fabric's bandwidth instead of the matrix pipe's rate.
+// Workspace = 256 slabs of one 256x256 fp32 tile + 256 8-byte flags behind them.
+// A flag is "raised" when it holds (magic << 32 | call number): nothing has to be zeroed, and a stale or uninitialised flag
+// cannot match.  The timeout word lives in pinned host memory (one per process): a launch that gave up waiting sets it, and
+// every later GEMM call fails loudly instead of returning wrong numbers.
+constexpr int64_t SK_SLAB_BYTES = 256ll * 256 * 256 * 4;
+constexpr int64_t SK_FLAG_BYTES = 256 * 8;
+inline int* sk_err_word() {
+  static int* w = [] {
+    int* q = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&q), 64, hipHostMallocMapped) != hipSuccess || !q) return (int*)nullptr;
+    *q = 0;
+    return q;
+  }();
+  return w;
+}
+inline unsigned long long sk_next_want() {
+  static std::atomic<unsigned int> calls{0};
+  return (0x56C4B57Bull << 32) | (unsigned long long)(++calls);
+}
+template <bool MASKED>
+int launch_w4_streamk(GemmArgs a, int tiles_m, int tiles_n, int nk_all, void* ws, hipStream_t s) {
+  a.tiles_m = tiles_m; a.tiles_n = tiles_n; a.tile0 = 0; a.split_n = 1; a.k_splits = 0; a.tail_tiles = 0; a.grid = 256;
+  a.ws = (float*)ws;
+  a.sk_total = tiles_m * tiles_n * nk_all;
+  a.sk_flags = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + SK_SLAB_BYTES);
+  a.sk_want = sk_next_want();
+  a.sk_err = sk_err_word();
+  return launch_w4<8, 0, 8, MASKED, false, true>(a, s);
+}
+#endif
 
 // partial last wave as a split-K pair of launches: a = the launch of the tail's parent tiles (tile0, tail_tiles,
 // k_splits, ws set by the caller)
@@ -1501,6 +1642,15 @@ VLB_TUNABLE int g_tile_order = 3;   // GemmArgs::order: bit 0 column bands of 8,
 VLB_TUNABLE int g_order_auto = 1;   // pick_order's shape rule (A/B: variant bit 13 disables it)
 VLB_TUNABLE int g_stagger = 0;      // tools: start delay (10-ns ticks) of half the first-round workgroups (timing experiment)
 VLB_TUNABLE int g_tail_splitk = 1;  // ... or, when the caller passes a workspace, along K (A/B: variant bit 9 disables)
+#ifdef VLB_TOOLS
+int g_streamk = 0;                  // tools: 1 = ragged multi-round outputs as ONE stream-K launch (vlb_gemm_set_streamk; measured slower, see launch_w4_streamk)
+// true when the shape should run as ONE stream-K launch of 256-row tiles: more than one round, not a whole number of rounds,
+// few enough rounds that the ragged end matters (>= 8 full rounds: the round + tail plans lose < 2 %), every segment long enough
+inline bool sk_wanted(int tiles, int nk_all, int act, bool ws_ok) {
+  return g_streamk && ws_ok && sk_err_word() && act != VLB_ACT_SWIGLU_PAIR && tiles > 256 && tiles % 256 != 0 && tiles < 8 * 256 &&
+         nk_all >= 16;
+}
+#endif
 
 // Tile order for a shape.  The order decides which operand is swept once and which is re-read once per band, i.e. which
 // one has to come back out of the 256 MB Infinity Cache: order 3 (column bands: W once, A re-read per band) unless A is the
@@ -1671,7 +1821,11 @@ extern "C" int vlb_gemm_plan(int M, int N, int K, int K2, int with_workspace) {
   return (use192 ? 192 : 256) * 1000 + t.mode * 100 + t.splits;
 }
 
+#ifdef VLB_TOOLS
+extern "C" int64_t vlb_gemm_workspace_bytes(void) { return SK_SLAB_BYTES + SK_FLAG_BYTES; }   // + the stream-K experiment's flags
+#else
 extern "C" int64_t vlb_gemm_workspace_bytes(void) { return 256ll * 256 * 256 * 4; }   // <= 256 work items x one 256x256 fp32 tile
+#endif
 
 extern "C" int vlb_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                              const void* bias, const void* residual, int ldr, int act, const void* A2, int lda2,
@@ -1752,6 +1906,11 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, void* C, in
       const bool w4 = (g_variant == 3 || g_variant == 5 || g_variant == 6 || (g_variant >= 0x30 && g_variant < 0x40)) && fits32 && K + K2 >= 4096;    // 6 (A/B): never 192-row tiles
 #else
       const bool w4 = (g_variant == 3 || g_variant == 5) && fits32 && K + K2 >= 4096;      // four-wave kernel shapes
+#endif
+#ifdef VLB_TOOLS
+      // tools A/B: ragged multi-round output as ONE stream-K launch of 256-row tiles instead of rounds + a re-cut / split-K tail or 192-row tiles
+      if (w4 && g_force_tile == 0 && g_variant == 3 && K % 64 == 0 && K2 % 64 == 0 && sk_wanted(tiles, (K + K2) / 64, act, ws_ok))
+        return launch_w4_streamk<false>(a, tm, tn, (K + K2) / 64, ws, s);
 #endif
       const int tm192 = (M + 191) / 192, tiles192 = tm192 * tn;
       TailPlan p256, p192;
@@ -1881,6 +2040,10 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
   TailPlan p256, p192;
   // (no split-K for the 256-row masked kernel: with 64 accumulator tiles + the mask temporaries the register
   // allocator starts rotating accumulator tuples behind the asm MFMAs; 192-row tiles are fine)
+#ifdef VLB_TOOLS
+  if (g_force_tile == 0 && sk_wanted(((M + 255) / 256) * tn, (K + 64) / 64, act, ws_ok))
+    return launch_w4_streamk<true>(a, (M + 255) / 256, tn, (K + 64) / 64, ws, s);
+#endif
   bool use192 = plan_rows(M, N, K + 64, ws_ok, p256, p192, false);
 #ifdef VLB_TOOLS
   if (g_force_tile == 3) use192 = false;      // A/B only: force 256- / 192-row tiles for the masked-pair kernel
@@ -1907,6 +2070,7 @@ static int masked_pair_impl(const void* A, int lda, const void* W, int ldw, void
 #ifdef VLB_TOOLS
 // tuning hooks, libvlb_tools.so only: kernel variant / forced tile
 extern "C" void vlb_gemm_set_stagger(int ticks) { g_stagger = ticks; }
+extern "C" void vlb_gemm_set_streamk(int on) { g_streamk = on; }
 extern "C" void vlb_gemm_set_rowsplit(int on) { g_w4_rowsplit = on; }
 extern "C" void vlb_gemm_set_persist(int on) { g_w4_persist = on; }
 extern "C" void vlb_gemm_set_wd(int on) { g_wd = on; }

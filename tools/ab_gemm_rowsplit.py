@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phantom_vlb_amd import ops
 from phantom_vlb_amd._lib import lib
 MODE = os.environ.get("VLB_AB", "rowsplit")             # rowsplit | persist (the persistent-stream experiment, ABL bit 7) | wd (W-direct kernel on / off)
-setter = {"persist": lib.vlb_gemm_set_persist, "wd": lib.vlb_gemm_set_wd}.get(MODE, lib.vlb_gemm_set_rowsplit)
+setter = {"persist": lib.vlb_gemm_set_persist, "wd": lib.vlb_gemm_set_wd, "streamk": lib.vlb_gemm_set_streamk}.get(MODE, lib.vlb_gemm_set_rowsplit)    # streamk: 0 = the round + tail plans, 1 = one stream-K launch (the product's choice)
 setter.argtypes = [ctypes.c_int]; setter.restype = None
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 M = int(os.environ.get("VLB_ROWS", 5861))
@@ -64,6 +64,10 @@ cases = {
     "down fwd + residual (K=14336)": lambda: ops.gemm(hh, wd, residual=res),
     "dgrad gate/up (K=28672)": lambda: ops.gemm(dgu, wgut),
     "dgrad down plain": lambda: ops.gemm(dy, wt),
+    "qkv + LoRA pair": lambda: ops.gemm(x, wqkv, a2=tl, w2=bp[:6144]),
+    "o + residual + LoRA pair": lambda: ops.gemm(x, wo, residual=res, a2=tl, w2=bp[:4096]),
+    "dgrad qkv (K=6144)": lambda: ops.gemm(dgu[:, :6144], wgut[:, :6144]),
+    "dgrad o masked pair": lambda: ops.gemm_masked_pair(dy, wo, u, At[:4096], 0.1, 4321),
     "dgrad down masked pair + swiglu bwd": lambda: ops.gemm_masked_pair_swiglu_bwd(dy, wt, gu, u, At, 0.1, 1234),
 }
 only = os.environ.get("VLB_CASE")
