@@ -258,3 +258,22 @@ def test_bench_gpus_2_launches_two_ranks(dev):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "mini"],
                            capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
         assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+def test_bench_gpus_2_full_finetune_runs_full_shard(dev):
+    """`python bench.py --gpus 2 --workload full` (mini geometry, gloo rehearsal on one GPU): the trained decoder weights run
+    FULL_SHARD (fsdp.yaml:11) by default and the line says so; VLB_FSDP_STRATEGY=SHARD_GRAD_OP keeps them replicated."""
+    import json
+    import subprocess
+    for strategy, word in ((None, "FULL_SHARD"), ("SHARD_GRAD_OP", "replicated (SHARD_GRAD_OP")):
+        env = dict(os.environ, VLB_DIST_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VLB_FSDP_STRATEGY"):
+            env.pop(k, None)
+        if strategy:
+            env["VLB_FSDP_STRATEGY"] = strategy
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "mini", "--workload", "full",
+                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["n_gpus"] == 2 and out["value"] > 0
+        assert "trained decoder weights " + word in out["config"]["parallelism"], out["config"]["parallelism"]
