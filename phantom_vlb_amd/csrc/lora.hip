@@ -482,9 +482,15 @@ inline uint32_t thresh16(float p) {
 }
 }  // namespace
 
+// Row splits of the skinny wgrad sweeps (grid = K/256 column blocks x splits).  Small M: >= 256 rows (8 MFMA k-steps) per split.
+// From 4096 rows on: 32 splits (>= 128 rows each), so that the grid is K/8 workgroups - a whole number of workgroups per CU for
+// every K that is a multiple of 2048 (4096: 2 per CU, 6144: 3, 14336: 7, 28672: 14).  With ceil(M/256) = 23 splits at the LoRA batch
+// the K = 4096 sweeps ran 368 workgroups on 256 CUs (112 CUs with two, 144 with one), and the hash-bound ones took as long as
+// their doubly loaded CUs.
 extern "C" int vlb_wgrad_splits(int M) {
-  int s = (M + 255) / 256;                 // >= 256 rows (8 MFMA k-steps) per split
-  return s < 1 ? 1 : (s > 32 ? 32 : s);
+  if (M >= 4096) return 32;
+  int s = (M + 255) / 256;
+  return s < 1 ? 1 : s;
 }
 
 extern "C" int vlb_wgrad_skinny(const void* G, int ldg, const void* X, int ldx, float* dW, float* ws, int M, int N, int K,
