@@ -726,8 +726,9 @@ __device__ __forceinline__ int w4_epilogue_kind(const GemmArgs& p) {
 // stores and loads - the instructions the gfx942 / gfx950 memory model uses for agent-scope atomics - ordered by vmcnt(0) +
 // a workgroup barrier on the writing side and by the flag load + barrier on the reading side; no cache-wide write-back or
 // invalidate (see the contributor branch).
-template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false, bool SPLITK = false, bool STREAMK = false>
+template <int NT = 8, int ABL = 0, int MT = 8, bool MASKED = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+  constexpr bool STREAMK = (ABL & 256) != 0;           // (an ABL bit, not a template parameter of its own: the product kernels keep their names)
   constexpr int TM = 16 * MT, TN = 16 * NT, BM = 2 * TM, BN = 2 * TN;
   constexpr int NG = MT * NT / 4;                      // groups of 4 MFMAs per block (one k-step of the wave block)
   constexpr int LAST_A = NG / 2 + 1;                   // group in which the double-slotted last A fragment is fetched
@@ -1523,8 +1524,9 @@ inline int launch_wd(GemmArgs& a, hipStream_t s) {
 }
 #endif
 
-template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false, bool STREAMK = false>
+template <int NT, int ABL, int MT = 8, bool MASKED = false, bool SPLITK = false>
 int launch_w4(GemmArgs& a, hipStream_t s) {
+  constexpr bool STREAMK = (ABL & 256) != 0;
 #ifdef VLB_TOOLS
   if constexpr (NT == 8 && ABL == 0 && MT == 8 && !MASKED && !SPLITK && !STREAMK) {
     if (g_wd && a.split_n == 1 && a.k_splits <= 1) return launch_wd(a, s);
@@ -1532,7 +1534,7 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
 #endif
   constexpr int LDS = 2 * (32 * MT + 32 * NT) * ROW_BYTES;
   // once per process and kernel; a function-local static's initialisation is thread-safe (C++11)
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK, STREAMK>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr != hipSuccess) {
     vlb_set_error("gemm: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(attr));
@@ -1570,7 +1572,7 @@ int launch_w4(GemmArgs& a, hipStream_t s) {
     }
   }
 #endif
-  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK, STREAMK>), dim3(a.grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<NT, ABL, MT, MASKED, SPLITK>), dim3(a.grid), dim3(256), LDS, s, a);
   VLB_LAUNCH_CHECK();
   return VLB_OK;
 }
@@ -1607,7 +1609,7 @@ int launch_w4_streamk(GemmArgs a, int tiles_m, int tiles_n, int nk_all, void* ws
   a.sk_flags = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + SK_SLAB_BYTES);
   a.sk_want = sk_next_want();
   a.sk_err = sk_err_word();
-  return launch_w4<8, 0, 8, MASKED, false, true>(a, s);
+  return launch_w4<8, 256, 8, MASKED, false>(a, s);
 }
 #endif
 

@@ -116,8 +116,9 @@ def audit(asm_path):
         if "gemm_w4_kernel" not in name:
             continue
         body = lines[i:min(x for x in ends if x > i)]
-        tmpl = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)E", name)
-        nt, _, mt, masked, splitk, streamk = (int(x) for x in tmpl.groups())
+        tmpl = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", name)
+        nt, abl, mt, masked, splitk = (int(x) for x in tmpl.groups())
+        streamk = int(bool(abl & 256))               # tools build: the stream-K experiment (its segment loop wraps the K loop: only the innermost loop is the K loop)
         loops = list(k_loops(body))
         want_mfma = 2 * mt * nt                         # two k-steps of MT x NT fragments per K-tile
         for seg in loops:
@@ -128,6 +129,8 @@ def audit(asm_path):
             n_rd = sum("ds_read_b128" in l for l in seg)
             report.append(f"gemm_w4_kernel<NT={nt}, MT={mt}, masked={masked}, splitk={splitk}, streamk={streamk}>: K loop {n_mfma} MFMA, {n_dma} LDS-DMA, "
                           f"{n_rd} ds_read_b128, {n_scr} scratch, {n_acc} v_accvgpr")
+            if streamk and n_mfma > want_mfma:
+                continue                             # the segment loop around the K loop (holds the peeled tiles and the epilogues)
             if n_mfma != want_mfma or n_scr or n_acc or n_dma != 2 * (mt + nt) // 2 or n_rd != 2 * (mt + nt):
                 bad.append(report[-1])
         if not loops and not splitk:
